@@ -1,0 +1,56 @@
+/*
+ * Network.h -- host-side boundary types of the ViT inference path.
+ *
+ * ABI contract: the two structs below must keep the exact field order, types
+ * and sizes of the reference's declarations so that its Main.c / comparator.c
+ * link against this library unchanged:
+ *   ImageData  <- reference MulticoreMainProject/Network.h:7-14
+ *   Network    <- reference MulticoreMainProject/Network.h:19-23
+ * (tests/test_abi.py checks sizeof/offsetof against the reference header when
+ * /root/reference is present, and against the hard numbers below otherwise.)
+ *
+ * Unlike the reference header this one defines no globals (the reference
+ * defines ~30 unused timer variables in the header, Network.h:25-34, which
+ * forces -fcommon on multi-TU links).
+ */
+#ifndef VIT_HIP_NETWORK_H
+#define VIT_HIP_NETWORK_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One image. An array of `n` of these is passed around; every element carries
+ * the same n/c/h/w (reference Network.c:86-89) and owns a separately
+ * malloc'd planar C x H x W fp32 buffer (reference Network.c:90).
+ * x86-64 layout: 4 ints at 0,4,8,12; pointer at 16; sizeof == 24. */
+typedef struct
+{
+    int n;       /* number of images in the array this element belongs to */
+    int c;       /* channels */
+    int h;       /* height */
+    int w;       /* width */
+    float *data; /* c*h*w floats, channel-major (CHW) */
+} ImageData;
+
+/* One weight tensor: host pointer + element count (not bytes).
+ * x86-64 layout: pointer at 0, size_t at 8; sizeof == 16. */
+typedef struct
+{
+    float *data;
+    size_t size;
+} Network;
+
+/* POSIX implementations of the reference loaders (same names, argument
+ * meaning and on-disk formats: reference Network.c:26 and Network.c:134).
+ * Defined in vit-with-opencl_amd/csrc/Network_posix.c. */
+ImageData *load_image_data(const char *filename);
+void load_weights(const char *directory, Network network[], int count);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* VIT_HIP_NETWORK_H */

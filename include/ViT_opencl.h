@@ -1,0 +1,111 @@
+/*
+ * ViT_opencl.h -- the drop-in entry point and the extended C API around it.
+ *
+ * `ViT_opencl` keeps the exact prototype of the reference
+ * (MulticoreMainProject/ViT_opencl.h:6, defined ViT_opencl.c:794, sole caller
+ * Main.c:54) so that Main.c and comparator.c link unchanged; behind it sits a
+ * batched HIP forward pass for gfx950 instead of 113 OpenCL launches per image.
+ * The name is kept for link compatibility only -- nothing here uses OpenCL.
+ *
+ * Differences from the reference that callers can rely on:
+ *   - synchronous: every probabilities[i] is complete on return
+ *     (the reference may return with the last read-back in flight,
+ *      ViT_opencl.c:775-778,978-985);
+ *   - repeatable and with no image cap (the reference is single-shot and
+ *     capped at 100 images, ViT_opencl.c:104-114,747);
+ *   - no dependence on the current directory (the reference reads *.cl from
+ *     CWD at run time, ViT_opencl.c:833-899).
+ */
+#ifndef VIT_HIP_VIT_OPENCL_H
+#define VIT_HIP_VIT_OPENCL_H
+
+#include "Network.h"
+#include "kernelHandler.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Model shape.  The reference hard-codes ViT-B/16 as #defines duplicated in
+ * ViT_seq.c:10-21 and ViT_opencl.c:13-24; here it is data. */
+typedef struct vit_config
+{
+    int img_size;    /* 224 */
+    int patch_size;  /* 16  */
+    int in_chans;    /* 3   */
+    int num_classes; /* 1000 */
+    int embed_dim;   /* 768 */
+    int depth;       /* 12  */
+    int num_heads;   /* 12  */
+    int mlp_hidden;  /* (int)(embed_dim * mlp_ratio) = 3072 */
+    double eps;      /* LayerNorm epsilon, a double literal in the reference (1e-6) */
+} vit_config;
+
+/* Fill `cfg` with a named preset: "vit_b_16" (the reference's only
+ * configuration), "vit_l_16", "vit_h_14".  Returns 0, or -1 for an unknown name. */
+int vit_config_preset(vit_config *cfg, const char *name);
+
+/* Derived sizes. */
+int vit_config_tokens(const vit_config *cfg);      /* (img/patch)^2 + 1 */
+int vit_config_num_tensors(const vit_config *cfg); /* 4 + 12*depth + 4 (152 for B/16) */
+/* Element count tensor `idx` must have (torchvision state-dict order,
+ * reference index map: ViT_seq.c:437-513, ViT_opencl.c:159,280-295). */
+size_t vit_config_tensor_size(const vit_config *cfg, int idx);
+
+/* The drop-in symbol.  ViT-B/16 only, like the reference.  `image` is an
+ * array of image[0].n elements; `networks` the 152 host tensors;
+ * probabilities[i] receives 1000 post-softmax values.  Uses device
+ * $VIT_HIP_DEVICE (default 0).  On any device error: message + exit(EXIT_FAILURE),
+ * mirroring CHECK_ERROR. */
+void ViT_opencl(ImageData *image, Network *networks, float **probabilities);
+
+/* ---- extended API: resident weights, other configs, logits ---- */
+
+typedef struct vit_hip_ctx vit_hip_ctx;
+
+/* Upload `networks` (n_tensors host tensors, validated against cfg) to
+ * `device` once and size the activation arena for up to `max_batch` images per
+ * launch sequence.  What the reference redoes on every call inside its timed
+ * region (ViT_opencl.c:908-924) happens here, once. */
+int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
+                   int n_tensors, int device, int max_batch);
+void vit_hip_destroy(vit_hip_ctx *ctx);
+
+/* Host-pointer forward: gathers the n separately allocated images into pinned
+ * staging, runs them in chunks of <= max_batch, and returns when all outputs
+ * are in host memory.  `logits` ([n][num_classes], contiguous) and `probs`
+ * (n row pointers, as in the drop-in) may each be NULL. */
+int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *logits,
+                    float **probs);
+
+/* Device-resident forward: d_images is [n][C][H][W] fp32 already in HBM,
+ * n <= max_batch; d_logits / d_probs ([n][num_classes] device buffers) may each
+ * be NULL.  Asynchronous on `stream` (NULL = the context's own stream). */
+int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float *d_logits,
+                           float *d_probs, vh_stream_t stream);
+
+/* Introspection for tests / profiling. */
+const vit_config *vit_hip_config(const vit_hip_ctx *ctx);
+vh_stream_t vit_hip_stream(const vit_hip_ctx *ctx);
+int vit_hip_max_batch(const vit_hip_ctx *ctx);
+/* Device pointer of weight tensor idx (same index map as `networks`). */
+const float *vit_hip_weight(const vit_hip_ctx *ctx, int idx);
+/* Copy the residual stream left by the last forward ([n*tokens][embed]) to the host. */
+int vit_hip_read_tokens(vit_hip_ctx *ctx, int n, float *host_out);
+
+/* Deterministic synthetic data (counter-based integer PRNG -> exact fp32; no
+ * libm): dst[i] = offset + scale * u_i, u_i uniform in [-1,1) on a 2^-23 grid,
+ * fully determined by (seed, i).  Shared by tests, bench and the oracle
+ * harness so inputs are regenerated instead of stored. */
+void vit_synth_fill(float *dst, size_t count, unsigned long long seed, float scale, float offset);
+/* The synthetic-weight recipe of SURVEY 8d for tensor idx of cfg
+ * (seed = seed_base + idx); writes vit_config_tensor_size(cfg, idx) floats. */
+void vit_synth_tensor(const vit_config *cfg, int idx, unsigned long long seed_base, float *dst);
+/* Synthetic image: uniform in [-2,2), seed = 1000 + image_index. */
+void vit_synth_image(const vit_config *cfg, int image_index, float *dst);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* VIT_HIP_VIT_OPENCL_H */

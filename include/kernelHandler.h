@@ -1,0 +1,129 @@
+/*
+ * kernelHandler.h -- C ABI of the HIP device shim (libvit_hip.so).
+ *
+ * This is the replacement for the reference's OpenCL runtime glue
+ * (MulticoreMainProject/kernelHandler.h:6-18, kernelHandler.c:15,35) plus the
+ * clSetKernelArg/clEnqueueNDRangeKernel wrappers in ViT_opencl.c:361-779.
+ * The reference loads .cl text at run time (get_source_code) and JIT-builds it
+ * (build_error prints the log); here every kernel is compiled ahead of time
+ * for gfx950 and reached through one `vh_launch_*` entry per kernel.
+ *
+ * Everything is extern "C" with plain pointers and sizes: host code stays C.
+ * Device pointers are ordinary `float *` values that must not be dereferenced
+ * on the host.  All launchers are asynchronous on `stream` (0 = the null
+ * stream) and return 0 on success or a non-zero hipError_t value; the text of
+ * the most recent failure on the calling thread is at vh_last_error().
+ *
+ * There is no CPU fallback anywhere behind this header: without a usable
+ * gfx950 device vh_init() fails and every launcher returns an error.
+ */
+#ifndef VIT_HIP_KERNELHANDLER_H
+#define VIT_HIP_KERNELHANDLER_H
+
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *vh_stream_t; /* hipStream_t */
+typedef void *vh_event_t;  /* hipEvent_t  */
+
+/* Mirrors CHECK_ERROR (reference kernelHandler.h:6-10): print where, then
+ * exit(EXIT_FAILURE).  Used by the drop-in ViT_opencl(), which has no way to
+ * return a status; the extended vit_hip_* API returns the code instead. */
+#define VH_CHECK(err)                                                          \
+    do {                                                                       \
+        int vh_check_err_ = (err);                                             \
+        if (vh_check_err_ != 0) {                                              \
+            printf("[%s:%d] HIP error %d: %s\n", __FILE__, __LINE__,           \
+                   vh_check_err_, vh_last_error());                            \
+            exit(EXIT_FAILURE);                                                \
+        }                                                                      \
+    } while (0)
+
+/* ---- runtime (replaces clGetPlatformIDs..clCreateCommandQueue, ViT_opencl.c:799-861) ---- */
+int vh_device_count(void);                 /* number of visible HIP devices (0 if none / no driver) */
+int vh_init(int device);                   /* select `device`; fails unless it is a gfx950 part */
+const char *vh_last_error(void);           /* text of the last failure on this thread ("" if none) */
+const char *vh_device_name(void);          /* e.g. "AMD Instinct MI355X (gfx950, 256 CUs)" */
+
+int vh_stream_create(vh_stream_t *out);
+int vh_stream_destroy(vh_stream_t s);
+int vh_stream_sync(vh_stream_t s);         /* replaces clFinish */
+int vh_device_sync(void);
+
+int vh_event_create(vh_event_t *out);
+int vh_event_destroy(vh_event_t e);
+int vh_event_record(vh_event_t e, vh_stream_t s);
+int vh_event_sync(vh_event_t e);
+int vh_event_elapsed_ms(float *ms, vh_event_t start, vh_event_t stop);
+
+/* ---- memory (replaces clCreateBuffer / clEnqueueWriteBuffer / clEnqueueReadBuffer,
+ *      ViT_opencl.c:125-357, :371, :775) ---- */
+int vh_malloc(void **out, size_t bytes);
+int vh_free(void *p);
+int vh_host_alloc(void **out, size_t bytes); /* pinned host memory for async copies */
+int vh_host_free(void *p);
+int vh_memset(void *dst, int value, size_t bytes, vh_stream_t s);
+int vh_h2d(void *dst, const void *src, size_t bytes, vh_stream_t s); /* async w.r.t. host iff src is pinned */
+int vh_d2h(void *dst, const void *src, size_t bytes, vh_stream_t s);
+int vh_d2d(void *dst, const void *src, size_t bytes, vh_stream_t s);
+
+/* ---- kernels: one launcher per HIP kernel ---- */
+
+/* Patch embedding, fused with flatten/transpose, class-token prepend and
+ * position-embedding add.  Replaces Conv2d + postConv2d (ViT_opencl.c:361-442;
+ * kernels conv2d_kernel conv2d.cl:1 and postprocess conv2d.cl:39; CPU
+ * Conv2d_seq..pos_emb_seq ViT_seq.c:25-118).
+ *   images   [n_images][in_chans][img][img]  fp32, contiguous
+ *   conv_w   [embed][in_chans][patch][patch], conv_b [embed]
+ *   cls      [embed], pos [tokens][embed]   (tokens = (img/patch)^2 + 1)
+ *   tokens   [n_images][tokens][embed]      output */
+int vh_launch_patch_embed(vh_stream_t s, const float *images, const float *conv_w,
+                          const float *conv_b, const float *cls_token, const float *pos_embed,
+                          float *tokens, int n_images, int in_chans, int img_size,
+                          int patch_size, int embed_dim);
+
+/* Row LayerNorm, y = (x-mean)*inv_std*w + b with var = E[x^2]-mean^2 and
+ * inv_std = 1/sqrt(var+eps) (eps added in double, ViT_seq.c:21,135).
+ * Replaces layer_norm (ViT_opencl.c:444-482; layerNorm layer_norm.cl:3; CPU
+ * layer_norm_seq ViT_seq.c:120).  Row r is read at input + r*in_row_stride and
+ * written at output + r*out_row_stride (strides in floats), so the final
+ * norm can run on the class-token rows only. */
+int vh_launch_layer_norm(vh_stream_t s, const float *input, const float *weight,
+                         const float *bias, float *output, int rows, int embed_dim,
+                         long in_row_stride, long out_row_stride, double eps);
+
+/* output[rowA][colB] = input[rowA][colA] . weight[colB][colA]^T + bias[colB],
+ * optionally followed by exact-erf GELU, optionally adding `residual`
+ * (same shape as output; may alias output).  Argument order and names follow
+ * the reference kernel linear_layer (ll.cl:7-16) and its host wrapper
+ * (ViT_opencl.c:622-672); it also replaces QKV (multihead.cl:3, colB = 3*embed,
+ * output rows are Q|K|V side by side) and encoderResidual (layer_norm.cl:55).
+ * CPU: linear_layer_seq ViT_seq.c:295, gelu :283, residual loops :348,:360. */
+int vh_launch_linear(vh_stream_t s, float *output, const float *weight, const float *input,
+                     const float *bias, int rowA, int colA, int colB, int doGelu,
+                     const float *residual);
+
+/* Scaled-dot-product attention over the fused QKV rows produced by
+ * vh_launch_linear (row = Q[embed] | K[embed] | V[embed]); per (image, head):
+ * softmax(Q K^T / sqrt(head_dim)) V, heads concatenated.  Replaces
+ * QKV_TO_SCOREV (multihead.cl:65-137, ViT_opencl.c:539-565); CPU
+ * multihead_attn_seq ViT_seq.c:192-262.
+ *   qkv    [n_images*tokens][3*embed],  output [n_images*tokens][embed] */
+int vh_launch_attention(vh_stream_t s, const float *qkv, float *output, int n_images,
+                        int tokens, int embed_dim, int num_heads);
+
+/* Row softmax with max subtraction: output[r][i] = exp(x-max)/sum.  Replaces
+ * Softmax (ViT_opencl.c:750-779; softMax miniSoftMax.cl:1); CPU Softmax_seq
+ * ViT_seq.c:372. */
+int vh_launch_softmax(vh_stream_t s, const float *input, float *output, int rows, int length);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* VIT_HIP_KERNELHANDLER_H */

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF.
+
+Runs oracle/_ref/ref_harness -- the reference's unmodified ViT_seq.c compiled in
+place by oracle/Makefile -- on the deterministic synthetic inputs of
+vit_synth_* (weights: seed_base 0; images: index i -> seed 1000+i) and stores
+its outputs as small fixtures.  Only possible in the build container (needs
+/root/reference); the fixtures are committed, the reference never travels.
+
+Why synthetic inputs: 36 of the reference's 152 weight files and
+Data/input-100.bin are absent from the snapshot (/root/reference/.MISSING_LARGE_BLOBS),
+so its pretrained goldens (Data/answer_result*.txt) cannot be reproduced.
+
+Fixtures (inputs are regenerated from seeds, never stored):
+  b16_full.npz    logits[4][1000], probs[4][1000] for synthetic images 0..3
+  b16_stages.npz  per-stage outputs for image 0 / layer 0: small tensors in full,
+                  large ones as a stride-37 sample plus fp64 sum and abs-sum
+  b16_answer_result.txt  Main.c-format result lines ("[i] label: L / prob: P")
+"""
+from __future__ import annotations
+
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import oracle as orc  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+STRIDE = 37
+N_IMAGES = 4
+
+
+def summarize(a: np.ndarray) -> dict[str, np.ndarray]:
+    a = a.ravel()
+    return {
+        "sample": a[::STRIDE].copy(),
+        "sum": np.array(a.astype(np.float64).sum()),
+        "abssum": np.array(np.abs(a.astype(np.float64)).sum()),
+        "count": np.array(a.size),
+    }
+
+
+def main() -> None:
+    orc.build()
+    if not orc.have_reference():
+        sys.exit("oracle/_ref/ref_harness missing: run in the build container (needs /root/reference)")
+    GOLD.mkdir(parents=True, exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        full = orc.run_reference("full", 0, N_IMAGES, 0, out_path=Path(td) / "full.bin")
+        stages = orc.run_reference("stages", 0, out_path=Path(td) / "stages.bin")
+
+    logits = full["logits"].reshape(N_IMAGES, 1000)
+    probs = full["probs"].reshape(N_IMAGES, 1000)
+    np.savez(GOLD / "b16_full.npz", logits=logits, probs=probs,
+             seed_base=np.array(0), first_image=np.array(0),
+             seconds_per_image=full["seconds_per_image"])
+
+    out = {}
+    for name in ("conv", "tokens", "ln", "mha", "mlp", "enc0"):
+        for k, v in summarize(stages[name]).items():
+            out[f"{name}_{k}"] = v
+    for name in ("head", "softmax", "gelu"):
+        out[name] = stages[name]
+    out["stride"] = np.array(STRIDE)
+    np.savez(GOLD / "b16_stages.npz", **out)
+
+    # Result lines exactly as Main.c:59-72 prints them, but with a per-image argmax
+    # (Main.c:59 never resets pred_idx).
+    with open(GOLD / "b16_answer_result.txt", "w") as f:
+        for i in range(N_IMAGES):
+            k = int(np.argmax(probs[i]))
+            f.write("[%d] label: %d / prob: %.6f\n" % (i, k, probs[i][k]))
+    print("wrote", sorted(p.name for p in GOLD.iterdir()))
+    print("argmax", logits.argmax(1), "top-2 margin", np.sort(logits, 1)[:, -1] - np.sort(logits, 1)[:, -2])
+
+
+if __name__ == "__main__":
+    main()

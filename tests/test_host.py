@@ -1,0 +1,186 @@
+"""CPU tests of the host side: ABI layout, exported symbols, config bookkeeping,
+synthetic-data determinism, loaders, sharding.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference/MulticoreMainProject")
+
+
+def test_library_loads_and_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    for sym in pkg.binding.EXPORTS:
+        assert hasattr(L, sym), f"libvit_hip.so does not export {sym}"
+
+
+def test_headers_declare_exactly_the_exports(pkg):
+    """Every function prototype in include/*.h is in EXPORTS (and vice versa)."""
+    import re
+    declared = set()
+    for h in (ROOT / "include").glob("*.h"):
+        text = re.sub(r"/\*.*?\*/", "", h.read_text(), flags=re.S)
+        text = re.sub(r"#define VH_CHECK.*?while \(0\)", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(vh_[a-z0-9_]+|vit_[a-z0-9_]+|ViT_opencl|load_image_data|load_weights)\s*\(", text))
+    declared -= {"vh_check_err_"}
+    assert declared == set(pkg.binding.EXPORTS)
+
+
+def test_struct_layout_is_the_reference_abi(pkg):
+    b = pkg.binding
+    assert C.sizeof(b.ImageData) == 24 and b.ImageData.data.offset == 16
+    assert [getattr(b.ImageData, f).offset for f in "nchw"] == [0, 4, 8, 12]
+    assert C.sizeof(b.Network) == 16 and b.Network.data.offset == 0 and b.Network.size.offset == 8
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference tree not present")
+def test_struct_layout_against_reference_header(tmp_path):
+    """Compile a probe that includes the reference's own Network.h next to ours and
+    static-asserts identical sizes/offsets (header only; nothing is copied)."""
+    src = tmp_path / "probe.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include "%s/Network.h"
+typedef ImageData RefImage; typedef Network RefNet;
+#define ImageData OurImage
+#define Network OurNet
+#define load_image_data our_load_image_data
+#define load_weights our_load_weights
+#include "%s/include/Network.h"
+_Static_assert(sizeof(RefImage) == sizeof(OurImage), "ImageData size");
+_Static_assert(offsetof(RefImage, data) == offsetof(OurImage, data), "ImageData.data");
+_Static_assert(offsetof(RefImage, w) == offsetof(OurImage, w), "ImageData.w");
+_Static_assert(sizeof(RefNet) == sizeof(OurNet), "Network size");
+_Static_assert(offsetof(RefNet, size) == offsetof(OurNet, size), "Network.size");
+int main(void) { return 0; }
+''' % (REF, ROOT))
+    subprocess.run(["gcc", "-fcommon", "-c", str(src), "-o", str(tmp_path / "probe.o")], check=True)
+
+
+def test_config_presets_and_tensor_sizes(pkg):
+    L, b = pkg.lib(), pkg.binding
+    cfg = pkg.preset("vit_b_16")
+    assert (cfg.img_size, cfg.patch_size, cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.mlp_hidden) == \
+        (224, 16, 768, 12, 12, 3072)
+    assert cfg.eps == 1e-6 and b.tokens(cfg) == 197
+    assert L.vit_config_num_tensors(C.byref(cfg)) == 152
+    size = lambda i: L.vit_config_tensor_size(C.byref(cfg), i)  # noqa: E731
+    # SURVEY Appendix B
+    assert [size(i) for i in (0, 1, 2, 3)] == [768, 589824, 768, 151296]
+    assert [size(4 + k) for k in range(12)] == [768, 768, 1769472, 2304, 589824, 768, 768, 768,
+                                                 2359296, 3072, 2359296, 768]
+    assert [size(i) for i in (148, 149, 150, 151)] == [768, 768, 768000, 1000]
+    assert size(152) == 0 and size(-1) == 0
+    total = sum(size(i) for i in range(152))
+    assert total == 86567656  # 86.57 M parameters
+    with pytest.raises(ValueError):
+        pkg.preset("vit_tiny")
+    h14 = pkg.preset("vit_h_14")
+    assert b.tokens(h14) == 257 and L.vit_config_num_tensors(C.byref(h14)) == 392
+
+
+def _np_synth(count, seed, scale, offset):
+    """numpy twin of vit_synth_fill (csrc/vit_config.c)."""
+    def mix(x):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        base = mix(np.array([seed], dtype=np.uint64))
+        u24 = (mix(base + np.arange(count, dtype=np.uint64)) >> np.uint64(40)).astype(np.int32)
+    u = u24.astype(np.float32) * np.float32(1.0 / 8388608.0) - np.float32(1.0)
+    return np.float32(offset) + np.float32(scale) * u
+
+
+def test_synthetic_data_is_deterministic_and_portable(pkg, oracle):
+    L, b = pkg.lib(), pkg.binding
+    a = np.empty(10007, dtype=np.float32)
+    L.vit_synth_fill(b.fptr(a), a.size, 1234, 0.25, 0.3)
+    assert np.array_equal(a, _np_synth(a.size, 1234, 0.25, 0.3))
+    assert np.array_equal(a, oracle.synth_fill(a.size, 1234, 0.25, 0.3))  # oracle build sees the same bytes
+    assert a.min() >= 0.05 and a.max() < 0.55 and abs(float(a.mean()) - 0.3) < 0.01
+    cfg = pkg.preset("vit_b_16")
+    img = pkg.synth_images(cfg, 5, 1)[0]
+    assert np.array_equal(img, oracle.synth_image(5)) and img.min() >= -2 and img.max() < 2
+    w = pkg.synth_weights(cfg, 0)
+    assert len(w) == 152 and np.array_equal(w[150], oracle.synth_weights(0)[150])
+
+
+def test_loaders_round_trip(pkg, tmp_path):
+    """load_image_data / load_weights read the reference's on-disk formats
+    (Network.c:41-71: 4 x int32 header; :111-132 index from file name; :208-211 rounding)."""
+    L, b = pkg.lib(), pkg.binding
+    imgs = np.arange(2 * 3 * 4 * 4, dtype=np.float32).reshape(2, 3, 4, 4) / 7
+    path = tmp_path / "input-2.bin"
+    assert L.vit_write_image_file(str(path).encode(), b.image_array(imgs), 2) == 0
+    raw = path.read_bytes()
+    assert np.array_equal(np.frombuffer(raw[:16], dtype=np.int32), [2, 3, 4, 4])
+    loaded = L.load_image_data(str(path).encode())
+    assert loaded[0].n == 2 and loaded[1].w == 4
+    got = np.ctypeslib.as_array(loaded[1].data, shape=(48,))
+    assert np.array_equal(got, imgs[1].ravel())
+    assert not L.load_image_data(str(tmp_path / "missing.bin").encode())
+
+    wdir = tmp_path / "Network"
+    wdir.mkdir()
+    w7 = np.array([0.1234564, -0.9999996, 1.5, 2.0000004], dtype=np.float32)
+    assert L.vit_write_weight_file(str(wdir).encode(), 7, b"encoder_layers_x_in_proj_bias", b.fptr(w7), 4) == 0
+    (wdir / "notes.txt").write_text("ignored")
+    (wdir / "Weight_99_too_big.bin").write_bytes(b"\0" * 8)
+    nets = (b.Network * 10)()
+    L.load_weights(str(wdir).encode(), nets, 10)
+    assert nets[7].size == 4 and not nets[0].data and nets[0].size == 0
+    got = np.ctypeslib.as_array(nets[7].data, shape=(4,))
+    t = (w7 * np.float32(1e6)).astype(np.float64)          # the fp32 product, exactly
+    r = np.copysign(np.floor(np.abs(t) + 0.5), t)          # roundf: half away from zero
+    expect = r.astype(np.float32) / np.float32(1e6)
+    assert np.array_equal(got, expect)
+
+
+def test_vit_hip_create_rejects_bad_tensors_before_touching_the_device(pkg):
+    L, b = pkg.lib(), pkg.binding
+    cfg = pkg.preset("vit_b_16")
+    nets = (b.Network * 152)()
+    ctx = C.c_void_p()
+    assert L.vit_hip_create(C.byref(ctx), C.byref(cfg), nets, 151, 0, 1) == 2   # wrong count
+    assert L.vit_hip_create(C.byref(ctx), C.byref(cfg), nets, 152, 0, 1) == 3   # NULL tensors
+    assert not ctx.value
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    """In the build container there is no device: vh_init must fail with a message,
+    and nothing computes on the CPU instead."""
+    L = pkg.lib()
+    if L.vh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    assert L.vh_init(0) != 0
+    assert b"no HIP device" in L.vh_last_error()
+    cfg = pkg.preset("vit_b_16")
+    with pytest.raises(pkg.VitHipError):
+        pkg.ViTHip(cfg, pkg.synth_weights(cfg, 0), device=0, max_batch=1)
+
+
+def test_product_path_never_touches_the_oracle():
+    """Nothing under vit-with-opencl_amd/ or include/ may import, include, link or call
+    anything under oracle/ (comments may mention it)."""
+    import re
+    pat = re.compile(r"import\s+oracle|from\s+oracle|oracle/|liboracle|oracle\.py|\bport_[a-z_0-9]+\s*\(|ref_harness")
+    files = [p for p in list((ROOT / "vit-with-opencl_amd").rglob("*")) + list((ROOT / "include").rglob("*"))
+             if p.is_file() and (p.suffix in {".py", ".c", ".h", ".hip"} or p.name == "Makefile")]
+    assert len(files) >= 10
+    for p in files:
+        assert not pat.search(p.read_text(errors="ignore")), p
+
+
+def test_shard_range_covers_batch_exactly_once(pkg):
+    for total in (1, 7, 512, 513, 4096):
+        for world in (1, 2, 3, 8):
+            spans = [pkg.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= (total + world - 1) // world

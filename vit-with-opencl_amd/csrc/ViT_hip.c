@@ -1,0 +1,295 @@
+/*
+ * ViT_hip.c -- host side of the ViT forward pass, in C, over the C-ABI device
+ * shim (include/kernelHandler.h).  This file is the counterpart of the
+ * reference's ViT_opencl.c host orchestration (Encoder :710-748, ViT_opencl
+ * :794-986) and of its device-memory management (:125-357), redesigned:
+ *
+ *  - the whole batch moves through each operator at once (M = n*tokens rows)
+ *    instead of one image at a time through 113 event-chained launches;
+ *  - weights are uploaded once per context into one HBM slab, activations live
+ *    in one arena sized at creation (the reference creates and destroys 14
+ *    cl_mem objects per image, ViT_opencl.c:929,962);
+ *  - one in-order stream, so no event graph is needed;
+ *  - the residual adds are folded into the projection epilogues and the final
+ *    LayerNorm runs on the class-token rows only (the reference normalises all
+ *    197 rows and uses one, ViT_opencl.c:951-955 / ViT_seq.c:506-511).
+ *
+ * Operator order per layer (ViT_seq.c:330-370):
+ *   y = LN1(x); qkv = y Win^T + bin; a = attention(qkv); x = x + (a Wout^T + bout);
+ *   y = LN2(x); h = gelu(y W1^T + b1); x = x + (h W2^T + b2)
+ */
+#include "ViT_opencl.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+struct vit_hip_ctx
+{
+    vit_config cfg;
+    int device;
+    int max_batch;
+    int tokens;
+    int n_tensors;
+    vh_stream_t stream;
+
+    float *w_slab;      /* all weights, one allocation */
+    float **w;          /* device pointer per tensor index */
+
+    /* activation arena (rows = max_batch * tokens) */
+    float *x;           /* residual stream      [rows][E]   */
+    float *y;           /* LayerNorm output     [rows][E]   */
+    float *attn;        /* attention output     [rows][E]   */
+    float *qkv;         /* fused Q|K|V          [rows][3E]  */
+    float *hid;         /* MLP hidden           [rows][F]   */
+    float *cls;         /* normalised CLS rows  [max_batch][E] */
+    float *d_logits;    /* [max_batch][classes] */
+    float *d_probs;     /* [max_batch][classes] */
+    float *d_images;    /* [max_batch][C][H][W] staging target for the host API */
+
+    /* pinned host staging for the host-pointer API */
+    float *h_images;
+    float *h_logits;
+    float *h_probs;
+};
+
+static double wall_seconds(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+const vit_config *vit_hip_config(const vit_hip_ctx *ctx) { return &ctx->cfg; }
+vh_stream_t vit_hip_stream(const vit_hip_ctx *ctx) { return ctx->stream; }
+int vit_hip_max_batch(const vit_hip_ctx *ctx) { return ctx->max_batch; }
+const float *vit_hip_weight(const vit_hip_ctx *ctx, int idx)
+{
+    return (idx >= 0 && idx < ctx->n_tensors) ? ctx->w[idx] : NULL;
+}
+
+void vit_hip_destroy(vit_hip_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    if (ctx->stream)
+        vh_stream_sync(ctx->stream);
+    float *dev[] = {ctx->w_slab, ctx->x, ctx->y, ctx->attn, ctx->qkv, ctx->hid,
+                    ctx->cls, ctx->d_logits, ctx->d_probs, ctx->d_images};
+    for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); ++i)
+        if (dev[i])
+            vh_free(dev[i]);
+    float *host[] = {ctx->h_images, ctx->h_logits, ctx->h_probs};
+    for (size_t i = 0; i < sizeof(host) / sizeof(host[0]); ++i)
+        if (host[i])
+            vh_host_free(host[i]);
+    if (ctx->stream)
+        vh_stream_destroy(ctx->stream);
+    free(ctx->w);
+    free(ctx);
+}
+
+#define TRY(expr)                 \
+    do {                          \
+        int try_rc_ = (expr);     \
+        if (try_rc_ != 0) {       \
+            rc = try_rc_;         \
+            goto fail;            \
+        }                         \
+    } while (0)
+
+int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
+                   int n_tensors, int device, int max_batch)
+{
+    int rc = 0;
+    if (!out || !cfg || !networks || max_batch <= 0)
+        return 1;
+    *out = NULL;
+    if (n_tensors != vit_config_num_tensors(cfg))
+        return 2;
+    if (cfg->embed_dim % cfg->num_heads != 0 || cfg->img_size % cfg->patch_size != 0)
+        return 2;
+    /* The reference never checks its tensors (a missing file is a NULL
+     * dereference, Network.c:144-148); here a wrong count is an error. */
+    for (int i = 0; i < n_tensors; ++i)
+        if (!networks[i].data || networks[i].size != vit_config_tensor_size(cfg, i)) {
+            fprintf(stderr, "vit_hip_create: tensor %d has %zu elements, expected %zu\n", i,
+                    networks[i].data ? networks[i].size : (size_t)0, vit_config_tensor_size(cfg, i));
+            return 3;
+        }
+
+    vit_hip_ctx *ctx = (vit_hip_ctx *)calloc(1, sizeof(*ctx));
+    if (!ctx)
+        return 4;
+    ctx->cfg = *cfg;
+    ctx->device = device;
+    ctx->max_batch = max_batch;
+    ctx->tokens = vit_config_tokens(cfg);
+    ctx->n_tensors = n_tensors;
+    ctx->w = (float **)calloc((size_t)n_tensors, sizeof(float *));
+    if (!ctx->w) {
+        free(ctx);
+        return 4;
+    }
+
+    TRY(vh_init(device));
+    TRY(vh_stream_create(&ctx->stream));
+
+    /* one slab for all weights; 256-byte aligned tensors */
+    size_t total = 0;
+    for (int i = 0; i < n_tensors; ++i)
+        total += align_up(networks[i].size * sizeof(float), 256);
+    TRY(vh_malloc((void **)&ctx->w_slab, total));
+    size_t off = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        ctx->w[i] = (float *)((char *)ctx->w_slab + off);
+        TRY(vh_h2d(ctx->w[i], networks[i].data, networks[i].size * sizeof(float), ctx->stream));
+        off += align_up(networks[i].size * sizeof(float), 256);
+    }
+
+    const size_t E = (size_t)cfg->embed_dim, F = (size_t)cfg->mlp_hidden, NC = (size_t)cfg->num_classes;
+    const size_t rows = (size_t)max_batch * ctx->tokens;
+    const size_t img = (size_t)cfg->in_chans * cfg->img_size * cfg->img_size;
+    TRY(vh_malloc((void **)&ctx->x, rows * E * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->y, rows * E * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->attn, rows * E * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->qkv, rows * 3 * E * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->hid, rows * F * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->cls, (size_t)max_batch * E * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->d_logits, (size_t)max_batch * NC * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->d_probs, (size_t)max_batch * NC * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->d_images, (size_t)max_batch * img * sizeof(float)));
+    TRY(vh_host_alloc((void **)&ctx->h_images, (size_t)max_batch * img * sizeof(float)));
+    TRY(vh_host_alloc((void **)&ctx->h_logits, (size_t)max_batch * NC * sizeof(float)));
+    TRY(vh_host_alloc((void **)&ctx->h_probs, (size_t)max_batch * NC * sizeof(float)));
+    TRY(vh_stream_sync(ctx->stream));
+    *out = ctx;
+    return 0;
+fail:
+    vit_hip_destroy(ctx);
+    return rc;
+}
+
+int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float *d_logits,
+                           float *d_probs, vh_stream_t stream)
+{
+    int rc = 0;
+    if (!ctx || !d_images || n <= 0 || n > ctx->max_batch)
+        return 1;
+    const vit_config *c = &ctx->cfg;
+    const int E = c->embed_dim, F = c->mlp_hidden, T = ctx->tokens, NC = c->num_classes;
+    const int rows = n * T;
+    vh_stream_t s = stream ? stream : ctx->stream;
+    float **w = ctx->w;
+
+    /* patch embedding + class token + position embedding (ViT_seq.c:437-443) */
+    TRY(vh_launch_patch_embed(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n, c->in_chans,
+                              c->img_size, c->patch_size, E));
+
+    for (int l = 0; l < c->depth; ++l) {
+        float **lw = w + 4 + 12 * l; /* ln1 w,b; in w,b; out w,b; ln2 w,b; fc1 w,b; fc2 w,b */
+        TRY(vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
+        TRY(vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+        TRY(vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+        TRY(vh_launch_linear(s, ctx->x, lw[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+        TRY(vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
+        TRY(vh_launch_linear(s, ctx->hid, lw[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+        TRY(vh_launch_linear(s, ctx->x, lw[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+    }
+
+    /* final LayerNorm on the class-token rows, classifier, softmax (ViT_seq.c:506-515) */
+    float **tw = w + 4 + 12 * c->depth;
+    float *logits = d_logits ? d_logits : ctx->d_logits;
+    TRY(vh_launch_layer_norm(s, ctx->x, tw[0], tw[1], ctx->cls, n, E, (long)T * E, E, c->eps));
+    TRY(vh_launch_linear(s, logits, tw[2], ctx->cls, tw[3], n, E, NC, 0, NULL));
+    if (d_probs)
+        TRY(vh_launch_softmax(s, logits, d_probs, n, NC));
+    return 0;
+fail:
+    return rc;
+}
+
+/* Debug/test hook: copy the residual stream ([n*tokens][E]) to the host. */
+int vit_hip_read_tokens(vit_hip_ctx *ctx, int n, float *host_out)
+{
+    int rc = vh_d2h(host_out, ctx->x, (size_t)n * ctx->tokens * ctx->cfg.embed_dim * sizeof(float),
+                    ctx->stream);
+    return rc ? rc : vh_stream_sync(ctx->stream);
+}
+
+int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *logits, float **probs)
+{
+    int rc = 0;
+    if (!ctx || !images || n <= 0)
+        return 1;
+    const vit_config *c = &ctx->cfg;
+    const size_t img = (size_t)c->in_chans * c->img_size * c->img_size;
+    const size_t NC = (size_t)c->num_classes;
+
+    for (int first = 0; first < n; first += ctx->max_batch) {
+        const int m = (n - first < ctx->max_batch) ? n - first : ctx->max_batch;
+        /* gather the separately malloc'd images (Network.c:90) into pinned staging */
+        for (int i = 0; i < m; ++i) {
+            const ImageData *im = &images[first + i];
+            if (!im->data || im->c != c->in_chans || im->h != c->img_size || im->w != c->img_size)
+                return 5;
+            memcpy(ctx->h_images + (size_t)i * img, im->data, img * sizeof(float));
+        }
+        TRY(vh_h2d(ctx->d_images, ctx->h_images, (size_t)m * img * sizeof(float), ctx->stream));
+        TRY(vit_hip_forward_device(ctx, ctx->d_images, m, ctx->d_logits, probs ? ctx->d_probs : NULL,
+                                   ctx->stream));
+        if (logits)
+            TRY(vh_d2h(ctx->h_logits, ctx->d_logits, (size_t)m * NC * sizeof(float), ctx->stream));
+        if (probs)
+            TRY(vh_d2h(ctx->h_probs, ctx->d_probs, (size_t)m * NC * sizeof(float), ctx->stream));
+        TRY(vh_stream_sync(ctx->stream));
+        if (logits)
+            memcpy(logits + (size_t)first * NC, ctx->h_logits, (size_t)m * NC * sizeof(float));
+        if (probs)
+            for (int i = 0; i < m; ++i)
+                memcpy(probs[first + i], ctx->h_probs + (size_t)i * NC, NC * sizeof(float));
+    }
+    return 0;
+fail:
+    return rc;
+}
+
+/* The drop-in entry point (reference ViT_opencl.c:794).  Same observable
+ * behaviour: fills probabilities[i][0..999]; prints a setup-time line and a
+ * throughput line where the reference prints "setup time" / "picture #i". */
+void ViT_opencl(ImageData *image, Network *networks, float **probabilities)
+{
+    if (!image || !networks || !probabilities) {
+        printf("[%s:%d] ViT_opencl: NULL argument\n", __FILE__, __LINE__);
+        exit(EXIT_FAILURE);
+    }
+    const double t0 = wall_seconds();
+    vit_config cfg;
+    vit_config_preset(&cfg, "vit_b_16");
+    const int n = image[0].n;
+    int device = 0;
+    const char *env = getenv("VIT_HIP_DEVICE");
+    if (env && *env)
+        device = atoi(env);
+    int chunk = n < 512 ? n : 512;
+    const char *envb = getenv("VIT_HIP_MAX_BATCH");
+    if (envb && atoi(envb) > 0)
+        chunk = atoi(envb) < n ? atoi(envb) : n;
+
+    vit_hip_ctx *ctx = NULL;
+    int rc = vit_hip_create(&ctx, &cfg, networks, vit_config_num_tensors(&cfg), device, chunk);
+    if (rc != 0) {
+        printf("[%s:%d] vit_hip_create failed (%d): %s\n", __FILE__, __LINE__, rc, vh_last_error());
+        exit(EXIT_FAILURE);
+    }
+    const double t1 = wall_seconds();
+    printf("setup time: %.6f sec (%s)\n\n", t1 - t0, vh_device_name());
+    VH_CHECK(vit_hip_forward(ctx, image, n, NULL, probabilities));
+    const double t2 = wall_seconds();
+    printf("pictures #0..#%d: %.6f sec (%.1f images/sec)\n\n", n - 1, t2 - t1,
+           (double)n / (t2 - t1 > 0 ? t2 - t1 : 1e-9));
+    vit_hip_destroy(ctx);
+}

@@ -1,0 +1,173 @@
+/*
+ * rowops.hip -- the memory-bound row operators: LayerNorm and class softmax.
+ *
+ * LayerNorm replaces `layerNorm` (layer_norm.cl:3-53; host ViT_opencl.c:444-482),
+ * where three work-groups per row each recompute the row statistics and reduce
+ * through an 8-step LDS tree.  Here: one 64-lane wave per row, the row held in
+ * registers (one HBM read, one HBM write = the algorithmic 2*E*4 bytes per
+ * row), 16-byte coalesced loads, and __shfl_xor butterflies for the two sums.
+ * CPU statement: layer_norm_seq, ViT_seq.c:120-142 (single pass sum / sum of
+ * squares, var = E[x^2] - mean^2, eps added in double).
+ *
+ * Softmax replaces `softMax` (miniSoftMax.cl:1-50; host ViT_opencl.c:750-779):
+ * one 256-thread block per row of logits.  CPU statement: Softmax_seq,
+ * ViT_seq.c:372-397.
+ */
+#include "kernelHandler.h"
+#include "vit_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+/* NV = 16-byte chunks per lane; handles embed_dim <= 256*NV, embed_dim % 4 == 0. */
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta,
+                                                        float *__restrict__ out, int rows, int E,
+                                                        long in_stride, long out_stride, double eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows)
+        return;
+    const int nvec = E >> 2;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)row * in_stride);
+    f32x4 x[NV];
+    float sum = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int idx = c * 64 + lane;
+        if (idx < nvec) {
+            x[c] = src[idx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sum += x[c][e];
+                sq += x[c][e] * x[c][e];
+            }
+        }
+    }
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
+    const float mean = sum / (float)E;
+    const float var = sq / (float)E - mean * mean;
+    const float inv_std = 1.0f / sqrtf((float)((double)var + eps));
+
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(out + (size_t)row * out_stride);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int idx = c * 64 + lane;
+        if (idx < nvec) {
+            const f32x4 g = g4[idx], bb = b4[idx];
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                y[e] = (x[c][e] - mean) * inv_std * g[e] + bb[e];
+            dst[idx] = y;
+        }
+    }
+}
+
+constexpr int SM_THREADS = 256;
+constexpr int SM_MAX_PER_THREAD = 8; /* rows up to 2048 entries stay in registers */
+
+__global__ __launch_bounds__(SM_THREADS) void softmax_kernel(const float *__restrict__ in,
+                                                            float *__restrict__ out, int length)
+{
+    __shared__ float red[SM_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *src = in + (size_t)blockIdx.x * length;
+    float *dst = out + (size_t)blockIdx.x * length;
+
+    float v[SM_MAX_PER_THREAD];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_MAX_PER_THREAD; ++i) {
+        const int idx = tid + i * SM_THREADS;
+        v[i] = idx < length ? src[idx] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0)
+        red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SM_MAX_PER_THREAD; ++i) {
+        v[i] = expf(v[i] - mx); /* exp(-inf) = 0 for the padding */
+        sum += v[i];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0)
+        red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < SM_MAX_PER_THREAD; ++i) {
+        const int idx = tid + i * SM_THREADS;
+        if (idx < length)
+            dst[idx] = v[i] / sum;
+    }
+}
+
+} // namespace
+
+extern "C" int vh_launch_layer_norm(vh_stream_t s, const float *input, const float *weight,
+                                    const float *bias, float *output, int rows, int embed_dim,
+                                    long in_row_stride, long out_row_stride, double eps)
+{
+    if (!input || !weight || !bias || !output)
+        return vh_fail(1, "vh_launch_layer_norm: null pointer argument");
+    if (rows <= 0 || embed_dim <= 0 || embed_dim % 4 != 0 || embed_dim > 2048)
+        return vh_fail(1, "vh_launch_layer_norm: embed_dim=%d must be a multiple of 4, <= 2048", embed_dim);
+    if (in_row_stride % 4 != 0 || out_row_stride % 4 != 0 || in_row_stride < embed_dim ||
+        out_row_stride < embed_dim)
+        return vh_fail(1, "vh_launch_layer_norm: row strides must be multiples of 4 floats and >= embed_dim");
+    hipStream_t st = (hipStream_t)s;
+    const dim3 grid((rows + 3) / 4), block(256);
+    const int nv = (embed_dim / 4 + 63) / 64;
+#define VH_LN(NV)                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<NV>), grid, block, 0, st, input, weight, bias, output, \
+                       rows, embed_dim, in_row_stride, out_row_stride, eps)
+    if (nv <= 3) VH_LN(3);
+    else if (nv <= 4) VH_LN(4);
+    else if (nv <= 5) VH_LN(5);
+    else VH_LN(8);
+#undef VH_LN
+    VH_LAUNCH_CHECK("layernorm_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_softmax(vh_stream_t s, const float *input, float *output, int rows,
+                                 int length)
+{
+    if (!input || !output)
+        return vh_fail(1, "vh_launch_softmax: null pointer argument");
+    if (rows <= 0 || length <= 0 || length > SM_THREADS * SM_MAX_PER_THREAD)
+        return vh_fail(1, "vh_launch_softmax: length=%d must be in 1..%d", length,
+                       SM_THREADS * SM_MAX_PER_THREAD);
+    hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(SM_THREADS), 0, (hipStream_t)s, input, output,
+                       length);
+    VH_LAUNCH_CHECK("softmax_kernel");
+    return 0;
+}

@@ -1,0 +1,33 @@
+/*
+ * vit_kernels.h -- internal declarations shared by the HIP translation units.
+ * Not part of the public ABI (that is include/kernelHandler.h).
+ */
+#ifndef VIT_HIP_VIT_KERNELS_H
+#define VIT_HIP_VIT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+/* Records `msg` as the calling thread's last error and returns `code`. */
+int vh_fail(int code, const char *fmt, ...);
+/* Converts a hipError_t into the launcher return convention, recording text. */
+int vh_hip_status(hipError_t e, const char *what);
+
+#define VH_TRY(expr)                                                           \
+    do {                                                                       \
+        hipError_t vh_try_e_ = (expr);                                         \
+        if (vh_try_e_ != hipSuccess)                                           \
+            return vh_hip_status(vh_try_e_, #expr);                            \
+    } while (0)
+
+/* After a kernel launch: surface launch-configuration errors immediately. */
+#define VH_LAUNCH_CHECK(name)                                                  \
+    do {                                                                       \
+        hipError_t vh_lc_e_ = hipGetLastError();                               \
+        if (vh_lc_e_ != hipSuccess)                                            \
+            return vh_hip_status(vh_lc_e_, name);                              \
+    } while (0)
+
+#endif

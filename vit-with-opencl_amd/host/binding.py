@@ -1,0 +1,297 @@
+"""ctypes binding of libvit_hip.so -- test / bench plumbing over the C ABI.
+
+The product is the C library (include/*.h); this module only loads it, mirrors
+its structs, and turns non-zero status codes into exceptions.  There is no
+Python or CPU implementation of any operator here: if the library or a gfx950
+device is missing, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent.parent
+LIB_PATH = PKG_DIR / "libvit_hip.so"
+CSRC = PKG_DIR / "csrc"
+
+f32p = C.POINTER(C.c_float)
+voidp = C.c_void_p
+
+# Every symbol include/kernelHandler.h, include/ViT_opencl.h and include/Network.h declare.
+EXPORTS = [
+    "vh_device_count", "vh_init", "vh_last_error", "vh_device_name",
+    "vh_stream_create", "vh_stream_destroy", "vh_stream_sync", "vh_device_sync",
+    "vh_event_create", "vh_event_destroy", "vh_event_record", "vh_event_sync", "vh_event_elapsed_ms",
+    "vh_malloc", "vh_free", "vh_host_alloc", "vh_host_free", "vh_memset", "vh_h2d", "vh_d2h", "vh_d2d",
+    "vh_launch_patch_embed", "vh_launch_layer_norm", "vh_launch_linear", "vh_launch_attention",
+    "vh_launch_softmax",
+    "vit_config_preset", "vit_config_tokens", "vit_config_num_tensors", "vit_config_tensor_size",
+    "ViT_opencl", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
+    "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
+    "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
+    "load_image_data", "load_weights",
+]
+
+
+class VitConfig(C.Structure):
+    """`vit_config` (include/ViT_opencl.h)."""
+
+    _fields_ = [
+        ("img_size", C.c_int), ("patch_size", C.c_int), ("in_chans", C.c_int),
+        ("num_classes", C.c_int), ("embed_dim", C.c_int), ("depth", C.c_int),
+        ("num_heads", C.c_int), ("mlp_hidden", C.c_int), ("eps", C.c_double),
+    ]
+
+
+class ImageData(C.Structure):
+    """`ImageData` (include/Network.h; reference Network.h:7-14)."""
+
+    _fields_ = [("n", C.c_int), ("c", C.c_int), ("h", C.c_int), ("w", C.c_int), ("data", f32p)]
+
+
+class Network(C.Structure):
+    """`Network` (include/Network.h; reference Network.h:19-23)."""
+
+    _fields_ = [("data", f32p), ("size", C.c_size_t)]
+
+
+class VitHipError(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile csrc/ into libvit_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.c")) + list(CSRC.glob("*.h")) + \
+        list((PKG_DIR.parent / "include").glob("*.h"))
+    stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
+    if force or stale:
+        r = subprocess.run(["make", "-C", str(CSRC), "-j8"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise VitHipError("building libvit_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libvit_hip.so (no silent fallback: a missing library is an error)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise VitHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C {CSRC})")
+    L = C.CDLL(str(LIB_PATH))
+    i, sz = C.c_int, C.c_size_t
+    L.vh_last_error.restype = C.c_char_p
+    L.vh_device_name.restype = C.c_char_p
+    L.vh_init.argtypes = [i]
+    L.vh_stream_create.argtypes = [C.POINTER(voidp)]
+    L.vh_stream_destroy.argtypes = [voidp]
+    L.vh_stream_sync.argtypes = [voidp]
+    L.vh_event_create.argtypes = [C.POINTER(voidp)]
+    L.vh_event_destroy.argtypes = [voidp]
+    L.vh_event_record.argtypes = [voidp, voidp]
+    L.vh_event_sync.argtypes = [voidp]
+    L.vh_event_elapsed_ms.argtypes = [C.POINTER(C.c_float), voidp, voidp]
+    L.vh_malloc.argtypes = [C.POINTER(voidp), sz]
+    L.vh_free.argtypes = [voidp]
+    L.vh_host_alloc.argtypes = [C.POINTER(voidp), sz]
+    L.vh_host_free.argtypes = [voidp]
+    L.vh_memset.argtypes = [voidp, i, sz, voidp]
+    L.vh_h2d.argtypes = [voidp, voidp, sz, voidp]
+    L.vh_d2h.argtypes = [voidp, voidp, sz, voidp]
+    L.vh_d2d.argtypes = [voidp, voidp, sz, voidp]
+    L.vh_launch_patch_embed.argtypes = [voidp] + [voidp] * 6 + [i] * 5
+    L.vh_launch_layer_norm.argtypes = [voidp] + [voidp] * 4 + [i, i, C.c_long, C.c_long, C.c_double]
+    L.vh_launch_linear.argtypes = [voidp] + [voidp] * 4 + [i, i, i, i, voidp]
+    L.vh_launch_attention.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_softmax.argtypes = [voidp, voidp, voidp, i, i]
+    L.vit_config_preset.argtypes = [C.POINTER(VitConfig), C.c_char_p]
+    L.vit_config_tokens.argtypes = [C.POINTER(VitConfig)]
+    L.vit_config_num_tensors.argtypes = [C.POINTER(VitConfig)]
+    L.vit_config_tensor_size.argtypes = [C.POINTER(VitConfig), i]
+    L.vit_config_tensor_size.restype = sz
+    L.ViT_opencl.argtypes = [C.POINTER(ImageData), C.POINTER(Network), C.POINTER(f32p)]
+    L.ViT_opencl.restype = None
+    L.vit_hip_create.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i]
+    L.vit_hip_destroy.argtypes = [voidp]
+    L.vit_hip_destroy.restype = None
+    L.vit_hip_forward.argtypes = [voidp, C.POINTER(ImageData), i, f32p, C.POINTER(f32p)]
+    L.vit_hip_forward_device.argtypes = [voidp, voidp, i, voidp, voidp, voidp]
+    L.vit_hip_stream.argtypes = [voidp]
+    L.vit_hip_stream.restype = voidp
+    L.vit_hip_max_batch.argtypes = [voidp]
+    L.vit_hip_weight.argtypes = [voidp, i]
+    L.vit_hip_weight.restype = voidp
+    L.vit_hip_read_tokens.argtypes = [voidp, i, f32p]
+    L.vit_synth_fill.argtypes = [f32p, sz, C.c_ulonglong, C.c_float, C.c_float]
+    L.vit_synth_fill.restype = None
+    L.vit_synth_tensor.argtypes = [C.POINTER(VitConfig), i, C.c_ulonglong, f32p]
+    L.vit_synth_tensor.restype = None
+    L.vit_synth_image.argtypes = [C.POINTER(VitConfig), i, f32p]
+    L.vit_synth_image.restype = None
+    L.load_image_data.argtypes = [C.c_char_p]
+    L.load_image_data.restype = C.POINTER(ImageData)
+    L.load_weights.argtypes = [C.c_char_p, C.POINTER(Network), i]
+    L.load_weights.restype = None
+    L.vit_write_image_file.argtypes = [C.c_char_p, C.POINTER(ImageData), i]
+    L.vit_write_weight_file.argtypes = [C.c_char_p, i, C.c_char_p, f32p, sz]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise VitHipError(f"{what} failed with status {rc}: {lib().vh_last_error().decode()}")
+
+
+def fptr(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags.c_contiguous, "need contiguous float32"
+    return a.ctypes.data_as(f32p)
+
+
+def preset(name: str) -> VitConfig:
+    cfg = VitConfig()
+    if lib().vit_config_preset(C.byref(cfg), name.encode()) != 0:
+        raise ValueError(f"unknown preset {name}")
+    return cfg
+
+
+def tokens(cfg: VitConfig) -> int:
+    return lib().vit_config_tokens(C.byref(cfg))
+
+
+def synth_weights(cfg: VitConfig, seed_base: int = 0) -> list[np.ndarray]:
+    L = lib()
+    out = []
+    for idx in range(L.vit_config_num_tensors(C.byref(cfg))):
+        a = np.empty(L.vit_config_tensor_size(C.byref(cfg), idx), dtype=np.float32)
+        L.vit_synth_tensor(C.byref(cfg), idx, seed_base, fptr(a))
+        out.append(a)
+    return out
+
+
+def synth_images(cfg: VitConfig, first: int, count: int) -> np.ndarray:
+    L = lib()
+    a = np.empty((count, cfg.in_chans, cfg.img_size, cfg.img_size), dtype=np.float32)
+    for i in range(count):
+        L.vit_synth_image(C.byref(cfg), first + i, fptr(a[i]))
+    return a
+
+
+def networks(weights: list[np.ndarray]):
+    arr = (Network * len(weights))()
+    for i, w in enumerate(weights):
+        arr[i].data = fptr(w)
+        arr[i].size = w.size
+    return arr
+
+
+def image_array(images: np.ndarray):
+    """[n][C][H][W] float32 -> ImageData[n] borrowing the numpy rows (like Network.c:86-90)."""
+    n, c, h, w = images.shape
+    arr = (ImageData * n)()
+    for i in range(n):
+        arr[i].n, arr[i].c, arr[i].h, arr[i].w = n, c, h, w
+        arr[i].data = fptr(images[i])
+    return arr
+
+
+class DeviceBuffer:
+    """A vh_malloc'd float buffer with explicit copies (no hidden host mirror)."""
+
+    def __init__(self, count: int):
+        self.count = int(count)
+        self.ptr = voidp()
+        check(lib().vh_malloc(C.byref(self.ptr), max(self.count, 1) * 4), "vh_malloc")
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        d = cls(a.size)
+        check(lib().vh_h2d(d.ptr, a.ctypes.data_as(voidp), a.size * 4, None), "vh_h2d")
+        check(lib().vh_device_sync(), "vh_device_sync")
+        return d
+
+    def to_numpy(self, shape=None) -> np.ndarray:
+        out = np.empty(self.count, dtype=np.float32)
+        check(lib().vh_d2h(out.ctypes.data_as(voidp), self.ptr, self.count * 4, None), "vh_d2h")
+        check(lib().vh_device_sync(), "vh_device_sync")
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            lib().vh_free(self.ptr)
+            self.ptr = voidp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ViTHip:
+    """Resident-weights context (vit_hip_create / forward / destroy)."""
+
+    def __init__(self, cfg: VitConfig, weights: list[np.ndarray], device: int = 0, max_batch: int = 64):
+        self.cfg = cfg
+        self.L = lib()
+        self._weights = weights  # keep host arrays alive during create
+        self.ctx = voidp()
+        rc = self.L.vit_hip_create(C.byref(self.ctx), C.byref(cfg), networks(weights), len(weights),
+                                   device, max_batch)
+        check(rc, "vit_hip_create")
+        self.max_batch = max_batch
+        self.tokens = tokens(cfg)
+
+    @property
+    def stream(self):
+        return self.L.vit_hip_stream(self.ctx)
+
+    def forward(self, images: np.ndarray):
+        """Host-pointer path: [n][C][H][W] -> (logits[n][classes], probs[n][classes])."""
+        images = np.ascontiguousarray(images, dtype=np.float32)
+        n, nc = images.shape[0], self.cfg.num_classes
+        logits = np.empty((n, nc), dtype=np.float32)
+        probs = np.empty((n, nc), dtype=np.float32)
+        rows = (f32p * n)(*[fptr(probs[i]) for i in range(n)])
+        check(self.L.vit_hip_forward(self.ctx, image_array(images), n, fptr(logits), rows), "vit_hip_forward")
+        return logits, probs
+
+    def forward_device(self, d_images, n: int, d_logits=None, d_probs=None, stream=None):
+        """Device-resident path; pointers are ints / c_void_p / DeviceBuffer.ptr."""
+        check(self.L.vit_hip_forward_device(self.ctx, d_images, n, d_logits, d_probs, stream),
+              "vit_hip_forward_device")
+
+    def sync(self):
+        check(self.L.vh_stream_sync(self.stream), "vh_stream_sync")
+
+    def read_tokens(self, n: int) -> np.ndarray:
+        out = np.empty((n * self.tokens, self.cfg.embed_dim), dtype=np.float32)
+        check(self.L.vit_hip_read_tokens(self.ctx, n, fptr(out)), "vit_hip_read_tokens")
+        return out
+
+    def close(self):
+        if self.ctx:
+            self.L.vit_hip_destroy(self.ctx)
+            self.ctx = voidp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous batch shard of rank `rank`: images [lo, hi).  Images never
+    interact (the reference processes them strictly one at a time,
+    ViT_opencl.c:926), so the batch dimension is the only partition."""
+    per = (total + world - 1) // world
+    lo = min(rank * per, total)
+    return lo, min(lo + per, total)
