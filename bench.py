@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the ViT-B/16 forward pass on N MI355X GPUs.
+
+A "step" is one pass of the hot path (patch-embed -> 12 encoder layers -> final
+LayerNorm -> classifier -> softmax) over one batch of 512 synthetic 224x224x3
+images per GPU, already resident in HBM when the timed region starts; with N > 1
+each step ends with the RCCL gather of the class logits to rank 0 (the only
+collective on the path).  Batches shard by image, weights are replicated, so
+per-GPU work is fixed as N grows ("weak").
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fc1
+GEMM, gemm_f32_kernel<A_ROWS, EPI_GELU>): algorithmic FLOPs per launch divided by
+its mean launch duration, measured with HIP events recorded on the launch stream
+inside the timed region.  `cpu_baseline` is the reference's own ViT_seq.c
+(oracle/_ref, built in the build container) or, failing that, the oracle port,
+timed on this box's host cores on a bounded sample; its logits for image 0 are
+also used to report the parity of the GPU result in the same run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW" (spec)
+
+
+def model_flops(cfg, tokens: int) -> dict[str, float]:
+    """Algorithmic FLOPs (2*MAC) per image, per operator class."""
+    E, F, H, L = cfg.embed_dim, cfg.mlp_hidden, cfg.num_heads, cfg.depth
+    D, T, NP = E // H, tokens, tokens - 1
+    K0 = cfg.in_chans * cfg.patch_size ** 2
+    return {
+        "patch_embed": 2.0 * NP * K0 * E,
+        "qkv_gemm": L * 2.0 * T * E * 3 * E,
+        "attention": L * 2.0 * 2 * H * T * T * D,
+        "out_proj_gemm": L * 2.0 * T * E * E,
+        "fc1_gemm": L * 2.0 * T * E * F,
+        "fc2_gemm": L * 2.0 * T * F * E,
+        "head_gemm": 2.0 * E * cfg.num_classes,
+    }
+
+
+def cpu_baseline(n_procs: int):
+    """Time the CPU path on this box: one synthetic image per process, n_procs at once.
+    Returns (dict for the JSON line, logits of image 0 or None)."""
+    harness = ROOT / "oracle" / "_ref" / "ref_harness"
+    with tempfile.TemporaryDirectory() as td:
+        if harness.exists() and os.access(harness, os.X_OK):
+            t0 = time.perf_counter()
+            procs = []
+            for i in range(n_procs):
+                out = Path(td) / f"img{i}.bin"
+                procs.append(subprocess.Popen([str(harness), "full", str(i), "1", "0", str(out)],
+                                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+            ok = all(p.wait(timeout=600) == 0 for p in procs)
+            dt = time.perf_counter() - t0
+            if ok:
+                from oracle.oracle import read_records
+                logits0 = read_records(Path(td) / "img0.bin")["logits"]
+                return ({"value": n_procs / dt, "unit": "images/sec", "cores": n_procs, "kind": "reference",
+                         "sample": f"{n_procs} synthetic image(s), one per process, through the reference's "
+                                   f"own ViT_seq.c (oracle/_ref), {dt:.1f} s wall"}, logits0)
+        # fall back to the oracle port in worker processes (still only a baseline / checker)
+        from oracle.oracle import Oracle
+        orc = Oracle("vit_b_16")
+        w = orc.synth_weights(0)
+        t0 = time.perf_counter()
+        logits0, _, _ = orc.forward(orc.synth_image(0), w)
+        dt = time.perf_counter() - t0
+        return ({"value": 1.0 / dt, "unit": "images/sec", "cores": 1, "kind": "port",
+                 "sample": f"1 synthetic image through oracle/vit_seq_port.c, {dt:.1f} s wall"}, logits0)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # before the library: one HIP runtime per process (binding.lib())
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    cfg = pkg.preset("vit_b_16")
+    tokens = pkg.binding.tokens(cfg)
+    B, NC = args.batch, cfg.num_classes
+
+    weights = pkg.synth_weights(cfg, 0)
+    model = pkg.ViTHip(cfg, weights, device=local_rank, max_batch=B)
+    L = pkg.lib()
+
+    # Synthetic batch, distinct images per rank: global image index = rank*B + i.  Generated
+    # in slices and uploaded once; the timed region starts with everything in HBM.
+    d_images = pkg.DeviceBuffer(B * cfg.in_chans * cfg.img_size * cfg.img_size)
+    per = cfg.in_chans * cfg.img_size * cfg.img_size
+    for lo in range(0, B, 64):
+        n = min(64, B - lo)
+        chunk = pkg.synth_images(cfg, rank * B + lo, n)
+        pkg.binding.check(L.vh_h2d(d_images.ptr.value + lo * per * 4, chunk.ctypes.data, n * per * 4, None), "vh_h2d")
+        pkg.binding.check(L.vh_device_sync(), "sync")
+
+    if world > 1:
+        t_logits = torch.empty(B, NC, device="cuda", dtype=torch.float32)
+        t_gather = [torch.empty(B, NC, device="cuda", dtype=torch.float32) for _ in range(world)] if rank == 0 else None
+        d_logits_ptr = t_logits.data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream   # launch on torch's stream: RCCL orders after it
+        d_probs = pkg.DeviceBuffer(B * NC)
+    else:
+        d_logits = pkg.DeviceBuffer(B * NC)
+        d_logits_ptr = d_logits.ptr
+        d_probs = pkg.DeviceBuffer(B * NC)
+        stream = model.stream
+
+    def step():
+        model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
+        if world > 1:
+            dist.gather(t_logits, t_gather, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            pkg.binding.check(L.vh_device_sync(), "sync")
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    model.profile_enable(args.steps)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = model.profile_read()
+    model.profile_enable(0)
+
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        flops = model_flops(cfg, tokens)
+        total_flops = sum(flops.values())
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+
+        kernels = {}
+        for name, (ms, cnt) in prof.items():
+            if cnt == 0:
+                continue
+            avg_ms = ms / cnt
+            entry = {"launches_per_step": cnt // args.steps, "avg_ms": round(avg_ms, 4),
+                     "share_of_step": round(ms / args.steps / ms_per_step, 4)}
+            if name in flops:
+                per_launch = flops[name] * B / (cnt // args.steps)
+                entry["tflops"] = round(per_launch / (avg_ms * 1e-3) / 1e12, 2)
+            elif name == "layer_norm":
+                # algorithmic bytes: read + write one [rows][E] fp32 tensor (final LN is tiny)
+                bytes_per = 2.0 * B * tokens * cfg.embed_dim * 4
+                entry["gbs"] = round(bytes_per / (avg_ms * 1e-3) / 1e9, 1)
+                entry["frac_hbm_peak"] = round(entry["gbs"] / PEAK_HBM_GBS, 4)
+            kernels[name] = entry
+
+        fc1_ms, fc1_cnt = prof["fc1_gemm"]
+        fc1_flops_per_launch = 2.0 * B * tokens * cfg.embed_dim * cfg.mlp_hidden
+        achieved = fc1_flops_per_launch / (fc1_ms / fc1_cnt * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel<A_ROWS,EPI_GELU> (fc1: M=%d N=%d K=%d)" %
+                    (B * tokens, cfg.mlp_hidden, cfg.embed_dim),
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+
+        # sanity of what was computed + parity against the CPU path in the same run
+        logits_dev = (t_gather[0] if world > 1 else None)
+        if world > 1:
+            logits0 = logits_dev[0].cpu().numpy()
+        else:
+            logits0 = d_logits.to_numpy((B, NC))[0]
+        probs0 = d_probs.to_numpy((B, NC))[0]
+        out = {
+            "metric": "images/sec ViT-B/16 224x224 bs512", "value": round(value, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"ViT-B/16 224x224 fp32 forward (patch-embed..softmax), batch {B} per GPU, "
+                                   f"device-resident inputs, random-init weights", "global_batch": world * B,
+                       "parallelism": f"dp{world} (batch shards, replicated weights, RCCL gather of logits)"},
+            "model_tflops": round(total_flops * B * args.steps * world / elapsed / 1e12, 2),
+            "model_frac_of_f32_mfma_peak": round(total_flops * B * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nproc = args.cpu_procs or max(1, min(os.cpu_count() or 1, 16))
+            base, ref_logits = cpu_baseline(nproc)
+            out["cpu_baseline"] = base
+            if ref_logits is not None:
+                out["parity"] = {"max_abs_dlogit_vs_ViT_seq": float(np.abs(logits0 - ref_logits).max()),
+                                 "argmax_equal": bool(int(logits0.argmax()) == int(ref_logits.argmax())),
+                                 "tolerance": 1e-4, "image": 0}
+        out["checks"] = {"logits_finite": bool(np.isfinite(logits0).all()),
+                         "prob_sum_image0": float(probs0.sum())}
+        print(json.dumps(out), flush=True)
+
+    model.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

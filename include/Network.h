@@ -49,6 +49,13 @@ typedef struct
 ImageData *load_image_data(const char *filename);
 void load_weights(const char *directory, Network network[], int count);
 
+/* Writers for the same on-disk formats (no reference counterpart; they exist so a
+ * synthetic ./Data + ./Network tree can be produced for the unchanged Main.c).
+ * Return 0 on success, -1 on an I/O error. */
+int vit_write_image_file(const char *filename, const ImageData *images, int n);
+int vit_write_weight_file(const char *directory, int idx, const char *name, const float *data,
+                          size_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,27 @@ const float *vit_hip_weight(const vit_hip_ctx *ctx, int idx);
 /* Copy the residual stream left by the last forward ([n*tokens][embed]) to the host. */
 int vit_hip_read_tokens(vit_hip_ctx *ctx, int n, float *host_out);
 
+/* Per-operator timing with HIP events recorded on the launch stream (the capability
+ * behind the reference's dead profileEvents/printEventProfile, ViT_opencl.c:988-1048).
+ * enable(ctx, k) sizes an event pool for k forwards (0 disables); read() waits for
+ * the recorded launches, returns the summed milliseconds and launch counts per
+ * operator class since the last read, and rewinds the pool. */
+enum vit_op_class
+{
+    VIT_OP_PATCH_EMBED = 0, /* patch-embed GEMM + class-token rows */
+    VIT_OP_LAYER_NORM,      /* every LayerNorm (2 per layer + final) */
+    VIT_OP_QKV,             /* fused Q|K|V projection GEMM */
+    VIT_OP_ATTENTION,       /* softmax(QK^T/sqrt(D))V */
+    VIT_OP_OUT_PROJ,        /* attention output projection + residual */
+    VIT_OP_FC1,             /* MLP fc1 + GELU */
+    VIT_OP_FC2,             /* MLP fc2 + residual */
+    VIT_OP_HEAD,            /* classifier GEMM */
+    VIT_OP_SOFTMAX,         /* class softmax */
+    VIT_OP_COUNT
+};
+int vit_hip_profile_enable(vit_hip_ctx *ctx, int max_forwards);
+int vit_hip_profile_read(vit_hip_ctx *ctx, double ms_sum[VIT_OP_COUNT], long launches[VIT_OP_COUNT]);
+
 /* Deterministic synthetic data (counter-based integer PRNG -> exact fp32; no
  * libm): dst[i] = offset + scale * u_i, u_i uniform in [-1,1) on a 2^-23 grid,
  * fully determined by (seed, i).  Shared by tests, bench and the oracle

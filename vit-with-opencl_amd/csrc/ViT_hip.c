@@ -25,6 +25,15 @@
 #include <string.h>
 #include <time.h>
 
+#define TRY(expr)                 \
+    do {                          \
+        int try_rc_ = (expr);     \
+        if (try_rc_ != 0) {       \
+            rc = try_rc_;         \
+            goto fail;            \
+        }                         \
+    } while (0)
+
 struct vit_hip_ctx
 {
     vit_config cfg;
@@ -52,7 +61,51 @@ struct vit_hip_ctx
     float *h_images;
     float *h_logits;
     float *h_probs;
+
+    /* optional per-operator timing with HIP events on the launch stream */
+    vh_event_t *prof_ev;   /* 2 events per recorded launch */
+    int *prof_class;       /* operator class per recorded launch */
+    int prof_cap;          /* launches the pool can hold */
+    int prof_used;         /* launches recorded since enable */
 };
+
+static int prof_begin(vit_hip_ctx *ctx, vh_stream_t s, int op_class)
+{
+    if (!ctx->prof_ev || ctx->prof_used >= ctx->prof_cap)
+        return -1;
+    const int slot = ctx->prof_used++;
+    ctx->prof_class[slot] = op_class;
+    vh_event_record(ctx->prof_ev[2 * slot], s);
+    return slot;
+}
+
+static void prof_end(vit_hip_ctx *ctx, vh_stream_t s, int slot)
+{
+    if (slot >= 0)
+        vh_event_record(ctx->prof_ev[2 * slot + 1], s);
+}
+
+/* Launch `call` bracketed by two events when profiling is enabled. */
+#define OP(op_class, call)                                  \
+    do {                                                    \
+        const int op_slot_ = prof_begin(ctx, s, op_class);  \
+        TRY(call);                                          \
+        prof_end(ctx, s, op_slot_);                         \
+    } while (0)
+
+static void prof_release(vit_hip_ctx *ctx)
+{
+    if (ctx->prof_ev) {
+        for (int i = 0; i < 2 * ctx->prof_cap; ++i)
+            if (ctx->prof_ev[i])
+                vh_event_destroy(ctx->prof_ev[i]);
+        free(ctx->prof_ev);
+        free(ctx->prof_class);
+    }
+    ctx->prof_ev = NULL;
+    ctx->prof_class = NULL;
+    ctx->prof_cap = ctx->prof_used = 0;
+}
 
 static double wall_seconds(void)
 {
@@ -77,6 +130,7 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
         return;
     if (ctx->stream)
         vh_stream_sync(ctx->stream);
+    prof_release(ctx);
     float *dev[] = {ctx->w_slab, ctx->x, ctx->y, ctx->attn, ctx->qkv, ctx->hid,
                     ctx->cls, ctx->d_logits, ctx->d_probs, ctx->d_images};
     for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); ++i)
@@ -91,15 +145,6 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
     free(ctx->w);
     free(ctx);
 }
-
-#define TRY(expr)                 \
-    do {                          \
-        int try_rc_ = (expr);     \
-        if (try_rc_ != 0) {       \
-            rc = try_rc_;         \
-            goto fail;            \
-        }                         \
-    } while (0)
 
 int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                    int n_tensors, int device, int max_batch)
@@ -186,27 +231,27 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     float **w = ctx->w;
 
     /* patch embedding + class token + position embedding (ViT_seq.c:437-443) */
-    TRY(vh_launch_patch_embed(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n, c->in_chans,
-                              c->img_size, c->patch_size, E));
+    OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n,
+                                                 c->in_chans, c->img_size, c->patch_size, E));
 
     for (int l = 0; l < c->depth; ++l) {
         float **lw = w + 4 + 12 * l; /* ln1 w,b; in w,b; out w,b; ln2 w,b; fc1 w,b; fc2 w,b */
-        TRY(vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
-        TRY(vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
-        TRY(vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-        TRY(vh_launch_linear(s, ctx->x, lw[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
-        TRY(vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
-        TRY(vh_launch_linear(s, ctx->hid, lw[8], ctx->y, lw[9], rows, E, F, 1, NULL));
-        TRY(vh_launch_linear(s, ctx->x, lw[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
+        OP(VIT_OP_QKV, vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+        OP(VIT_OP_ATTENTION, vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+        OP(VIT_OP_OUT_PROJ, vh_launch_linear(s, ctx->x, lw[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
+        OP(VIT_OP_FC1, vh_launch_linear(s, ctx->hid, lw[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+        OP(VIT_OP_FC2, vh_launch_linear(s, ctx->x, lw[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
     }
 
     /* final LayerNorm on the class-token rows, classifier, softmax (ViT_seq.c:506-515) */
     float **tw = w + 4 + 12 * c->depth;
     float *logits = d_logits ? d_logits : ctx->d_logits;
-    TRY(vh_launch_layer_norm(s, ctx->x, tw[0], tw[1], ctx->cls, n, E, (long)T * E, E, c->eps));
-    TRY(vh_launch_linear(s, logits, tw[2], ctx->cls, tw[3], n, E, NC, 0, NULL));
+    OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, tw[0], tw[1], ctx->cls, n, E, (long)T * E, E, c->eps));
+    OP(VIT_OP_HEAD, vh_launch_linear(s, logits, tw[2], ctx->cls, tw[3], n, E, NC, 0, NULL));
     if (d_probs)
-        TRY(vh_launch_softmax(s, logits, d_probs, n, NC));
+        OP(VIT_OP_SOFTMAX, vh_launch_softmax(s, logits, d_probs, n, NC));
     return 0;
 fail:
     return rc;
@@ -218,6 +263,53 @@ int vit_hip_read_tokens(vit_hip_ctx *ctx, int n, float *host_out)
     int rc = vh_d2h(host_out, ctx->x, (size_t)n * ctx->tokens * ctx->cfg.embed_dim * sizeof(float),
                     ctx->stream);
     return rc ? rc : vh_stream_sync(ctx->stream);
+}
+
+int vit_hip_profile_enable(vit_hip_ctx *ctx, int max_forwards)
+{
+    int rc = 0;
+    if (!ctx)
+        return 1;
+    TRY(vh_stream_sync(ctx->stream));
+    prof_release(ctx);
+    if (max_forwards <= 0)
+        return 0;
+    const int per_forward = 1 + 7 * ctx->cfg.depth + 3;
+    ctx->prof_cap = per_forward * max_forwards;
+    ctx->prof_ev = (vh_event_t *)calloc((size_t)2 * ctx->prof_cap, sizeof(vh_event_t));
+    ctx->prof_class = (int *)calloc((size_t)ctx->prof_cap, sizeof(int));
+    if (!ctx->prof_ev || !ctx->prof_class) {
+        prof_release(ctx);
+        return 4;
+    }
+    for (int i = 0; i < 2 * ctx->prof_cap; ++i)
+        TRY(vh_event_create(&ctx->prof_ev[i]));
+    return 0;
+fail:
+    prof_release(ctx);
+    return rc;
+}
+
+int vit_hip_profile_read(vit_hip_ctx *ctx, double ms_sum[VIT_OP_COUNT], long launches[VIT_OP_COUNT])
+{
+    int rc = 0;
+    if (!ctx || !ms_sum || !launches)
+        return 1;
+    for (int k = 0; k < VIT_OP_COUNT; ++k) {
+        ms_sum[k] = 0.0;
+        launches[k] = 0;
+    }
+    for (int i = 0; i < ctx->prof_used; ++i) {
+        float ms = 0.0f;
+        TRY(vh_event_sync(ctx->prof_ev[2 * i + 1]));
+        TRY(vh_event_elapsed_ms(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        ms_sum[ctx->prof_class[i]] += ms;
+        launches[ctx->prof_class[i]] += 1;
+    }
+    ctx->prof_used = 0;
+    return 0;
+fail:
+    return rc;
 }
 
 int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *logits, float **probs)

@@ -8,6 +8,7 @@ device is missing, calls fail loudly.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -31,8 +32,9 @@ EXPORTS = [
     "vit_config_preset", "vit_config_tokens", "vit_config_num_tensors", "vit_config_tensor_size",
     "ViT_opencl", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
     "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
+    "vit_hip_profile_enable", "vit_hip_profile_read",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
-    "load_image_data", "load_weights",
+    "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
 ]
 
 
@@ -84,6 +86,15 @@ def lib() -> C.CDLL:
         return _lib
     if not LIB_PATH.exists():
         raise VitHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C {CSRC})")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same
+    # SONAME as /opt/rocm's).  If torch is going to live in this process it must be
+    # loaded FIRST so that libvit_hip.so binds to the runtime torch uses -- otherwise
+    # torch-allocated HBM and our streams would belong to two different runtimes.
+    if os.environ.get("VIT_HIP_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(str(LIB_PATH))
     i, sz = C.c_int, C.c_size_t
     L.vh_last_error.restype = C.c_char_p
@@ -128,6 +139,8 @@ def lib() -> C.CDLL:
     L.vit_hip_weight.argtypes = [voidp, i]
     L.vit_hip_weight.restype = voidp
     L.vit_hip_read_tokens.argtypes = [voidp, i, f32p]
+    L.vit_hip_profile_enable.argtypes = [voidp, i]
+    L.vit_hip_profile_read.argtypes = [voidp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.vit_synth_fill.argtypes = [f32p, sz, C.c_ulonglong, C.c_float, C.c_float]
     L.vit_synth_fill.restype = None
     L.vit_synth_tensor.argtypes = [C.POINTER(VitConfig), i, C.c_ulonglong, f32p]
@@ -275,6 +288,19 @@ class ViTHip:
         out = np.empty((n * self.tokens, self.cfg.embed_dim), dtype=np.float32)
         check(self.L.vit_hip_read_tokens(self.ctx, n, fptr(out)), "vit_hip_read_tokens")
         return out
+
+    OP_NAMES = ["patch_embed", "layer_norm", "qkv_gemm", "attention", "out_proj_gemm", "fc1_gemm",
+                "fc2_gemm", "head_gemm", "softmax"]
+
+    def profile_enable(self, max_forwards: int):
+        check(self.L.vit_hip_profile_enable(self.ctx, max_forwards), "vit_hip_profile_enable")
+
+    def profile_read(self) -> dict[str, tuple[float, int]]:
+        """-> {operator: (summed ms, launches)} since the last read."""
+        k = len(self.OP_NAMES)
+        ms, cnt = (C.c_double * k)(), (C.c_long * k)()
+        check(self.L.vit_hip_profile_read(self.ctx, ms, cnt), "vit_hip_profile_read")
+        return {name: (ms[j], cnt[j]) for j, name in enumerate(self.OP_NAMES)}
 
     def close(self):
         if self.ctx:
