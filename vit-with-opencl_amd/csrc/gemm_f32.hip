@@ -22,11 +22,11 @@
  *    k = 8*kk + 4*(l>>5) + e in register e, and MFMA step e contracts the
  *    pair {e, 4+e}; A and W use the same permutation, so only the summation
  *    order inside an 8-wide k group differs from the scalar loop.
- *  - Global->register->LDS double buffering: the next K-tile's 8 x 16-B loads
- *    per thread are issued before the 64 MFMAs of the current tile and written
- *    to the other LDS stage afterwards; one barrier per K-tile.  At fp32 MFMA
- *    rate (4096 cycles of MFMA per wave per K-tile) this hides HBM/L2 latency
- *    with 2 blocks (8 waves) per CU.
+ *  - Global->register->LDS double buffering, issue-early / write-late: K-tile
+ *    t+2's 8 x 16-B loads per thread are issued right after K-tile t+1 has been
+ *    written to the free LDS stage at the START of step t, so a load has a whole
+ *    step (4096-8192 cycles of MFMA) to land and the LDS writes overlap the
+ *    MFMAs; one barrier per K-tile, 2 blocks (8 waves) per CU.
  *  - The accumulator starts at the bias, like the scalar loop it replaces
  *    (`sum = bias[o]`, ViT_seq.c:301), and the residual is added to the
  *    finished sum (ViT_seq.c:350,362).
@@ -37,12 +37,13 @@
 #include "kernelHandler.h"
 #include "vit_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = BK + 4;          /* padded LDS row length in floats */
 constexpr int TILE_F = BM * LDT;     /* floats per operand tile per stage */
-constexpr int NTHREADS = 256;
 constexpr size_t LDS_BYTES = sizeof(float) * 4 * TILE_F; /* 2 stages x (A,W) */
 
 enum { A_ROWS = 0, A_PATCH = 1 };
@@ -66,15 +67,57 @@ __device__ __forceinline__ int xcd_tile(int bid, int nwg)
     return start + idx;
 }
 
-__device__ __forceinline__ float gelu_exact(float x)
+/* Branch-free fp32 erf for the fc1 epilogue.  The scalar loop calls libm erff
+ * (ViT_seq.c:285); a device libm erff is two divergent branches of ~50 VALU
+ * instructions each, which made the GELU epilogue a third of the fc1 kernel.  Here:
+ *   |x| <  0.921875 : x + x*P(x^2)
+ *   otherwise       : sign(x) * (1 - exp(-t*Q(t))), t = min(|x|, 4)
+ * with P, Q least-squares fits on Chebyshev nodes (tools/fit_erf.py), both evaluated
+ * unconditionally and selected.  Measured there: max |this - erf| = 8.1e-8 and
+ * max |this - glibc erff| = 6.0e-8 (1 ulp at 0.5..1), glibc itself being 4.5e-8 off. */
+__device__ __forceinline__ float erf_f32(float x)
 {
-    /* ViT_seq.c:285 / ll.cl:4, same association order. */
-    return 0.5f * x * (1.0f + erff(x / sqrtf(2.0f)));
+    const float t = fminf(fabsf(x), 4.0f);
+    const float s = x * x;
+    float p = 8.392696327e-05f;
+    p = __builtin_fmaf(p, s, -8.148506167e-04f);
+    p = __builtin_fmaf(p, s, 5.201591644e-03f);
+    p = __builtin_fmaf(p, s, -2.685964666e-02f);
+    p = __builtin_fmaf(p, s, 1.128370017e-01f);
+    p = __builtin_fmaf(p, s, -3.761263490e-01f);
+    p = __builtin_fmaf(p, s, 1.283791661e-01f);
+    const float small = __builtin_fmaf(p, x, x);
+    float q = -9.613538623e-07f;
+    q = __builtin_fmaf(q, t, 3.291785833e-05f);
+    q = __builtin_fmaf(q, t, -4.882355570e-04f);
+    q = __builtin_fmaf(q, t, 4.262940958e-03f);
+    q = __builtin_fmaf(q, t, -2.504872903e-02f);
+    q = __builtin_fmaf(q, t, 1.077397019e-01f);
+    q = __builtin_fmaf(q, t, 6.342266202e-01f);
+    q = __builtin_fmaf(q, t, 1.128881097e+00f);
+    const float large = copysignf(1.0f - __expf(-t * q), x);
+    return fabsf(x) < 0.921875f ? small : large;
 }
 
-template <int AMODE, int EPI, bool NGUARD>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const GemmParams p)
+__device__ __forceinline__ float gelu_exact(float x)
 {
+    /* 0.5*x*(1+erf(x/sqrt(2))), ViT_seq.c:285 / ll.cl:4; the division by sqrt(2) is a
+     * multiplication by its fp32 reciprocal (<= 1 ulp on the erf argument). */
+    return 0.5f * x * (1.0f + erf_f32(x * 0.70710678118654752f));
+}
+
+/* NW = waves per workgroup: 4 (2x2 waves, 64x64 each) or 8 (2x4 waves, 64x32 each).
+ * Two workgroups are resident per CU either way (LDS), i.e. 2 or 4 waves per SIMD. */
+template <int AMODE, int EPI, bool NGUARD, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_f32_kernel(const GemmParams p)
+{
+    constexpr int NT = 64 * NW;          /* threads */
+    constexpr int WN = NW / 2;           /* waves along N */
+    constexpr int WCOLS = BN / WN;       /* columns per wave: 64 or 32 */
+    constexpr int JT = WCOLS / 32;       /* 32-wide MFMA column tiles per wave */
+    constexpr int RP = NT / 8;           /* rows staged per pass (8 x 16-B chunks per row) */
+    constexpr int CH = BM / RP;          /* staged chunks per thread per operand */
+
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tile = xcd_tile(blockIdx.x, p.mtiles * p.ntiles);
@@ -82,14 +125,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const GemmParams 
     const int n0 = (tile % p.ntiles) * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-    const int ld_row = tid >> 3, ld_kc = (tid & 7) * 4; /* staging: rows ld_row+32i, floats ld_kc..+3 */
+    const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
+    const int ld_row = tid >> 3, ld_kc = (tid & 7) * 4; /* staging: rows ld_row+RP*i, floats ld_kc..+3 */
 
-    /* Per-thread source rows for the four staged chunks of each operand. */
-    const float *a_src[4], *w_src[4];
+    /* Per-thread source rows for the staged chunks of each operand. */
+    const float *a_src[CH], *w_src[CH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = min(m0 + ld_row + 32 * i, p.M - 1);
+    for (int i = 0; i < CH; ++i) {
+        int m = min(m0 + ld_row + RP * i, p.M - 1);
         if (AMODE == A_ROWS) {
             a_src[i] = p.A + (size_t)m * p.K + ld_kc;
         } else {
@@ -99,16 +142,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const GemmParams 
             a_src[i] = p.A + ((size_t)b * p.chans * p.img + (size_t)oh * p.patch) * p.img +
                        (size_t)ow * p.patch;
         }
-        int n = n0 + ld_row + 32 * i;
+        int n = n0 + ld_row + RP * i;
         if (NGUARD)
             n = min(n, p.N - 1);
         w_src[i] = p.W + (size_t)n * p.K + ld_kc;
     }
 
-    f32x4 ra[4], rw[4];
+    f32x4 ra[CH], rw[CH];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < CH; ++i) {
             if (AMODE == A_ROWS) {
                 ra[i] = *reinterpret_cast<const f32x4 *>(a_src[i] + k0);
             } else {
@@ -125,17 +168,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const GemmParams 
     auto lstore = [&](int stage) {
         float *As = smem + stage * 2 * TILE_F, *Ws = As + TILE_F;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4 *>(As + (ld_row + 32 * i) * LDT + ld_kc) = ra[i];
-            *reinterpret_cast<f32x4 *>(Ws + (ld_row + 32 * i) * LDT + ld_kc) = rw[i];
+        for (int i = 0; i < CH; ++i) {
+            *reinterpret_cast<f32x4 *>(As + (ld_row + RP * i) * LDT + ld_kc) = ra[i];
+            *reinterpret_cast<f32x4 *>(Ws + (ld_row + RP * i) * LDT + ld_kc) = rw[i];
         }
     };
 
     /* Accumulators start at the bias (column = lane & 31 of each 32-wide tile). */
-    f32x16 acc[2][2];
+    f32x16 acc[2][JT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int col = n0 + wn * 64 + j * 32 + lr;
+    for (int j = 0; j < JT; ++j) {
+        int col = n0 + wn * WCOLS + j * 32 + lr;
         if (NGUARD)
             col = min(col, p.N - 1);
         const float bv = p.bias[col];
@@ -146,36 +189,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const GemmParams 
                 acc[i][j][r] = bv;
     }
 
+    /* K loop.  Invariant at the top of step kt: LDS stage kt&1 holds K-tile kt
+     * (visible to all waves), the staging registers hold (or are receiving) K-tile
+     * kt+1.  The other stage was last read in step kt-1 and every wave has passed
+     * the barrier since, so K-tile kt+1 is written there right away and the loads for
+     * K-tile kt+2 are re-issued into the same registers: the ds_writes and the
+     * global loads then sit among this step's MFMAs instead of in an MFMA-free
+     * tail, and the only exposed latency per step is barrier + first fragment read. */
+    auto compute_kk = [&](const float *a_base, const float *w_base, int kk) {
+        f32x4 a[2], b[JT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            a[i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+            b[j] = *reinterpret_cast<const f32x4 *>(w_base + j * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    };
+
     const int nk = p.K / BK;
     gload(0);
     lstore(0);
+    if (nk > 1)
+        gload(BK);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk)
-            gload((kt + 1) * BK);
-
         const float *As = smem + cur * 2 * TILE_F, *Ws = As + TILE_F;
         const float *a_base = As + (wm * 64 + lr) * LDT + lh * 4;
-        const float *w_base = Ws + (wn * 64 + lr) * LDT + lh * 4;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a_base + kk * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a_base + 32 * LDT + kk * 8);
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(w_base + kk * 8);
-            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(w_base + 32 * LDT + kk * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
-            }
-        }
+        const float *w_base = Ws + (wn * WCOLS + lr) * LDT + lh * 4;
 
-        if (kt + 1 < nk)
+        compute_kk(a_base, w_base, 0);
+        if (kt + 1 < nk) {
             lstore(cur ^ 1);
+            if (kt + 2 < nk)
+                gload((kt + 2) * BK);
+        }
+#pragma unroll
+        for (int kk = 1; kk < BK / 8; ++kk)
+            compute_kk(a_base, w_base, kk);
         __syncthreads();
     }
 
@@ -197,8 +256,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const GemmParams 
                 posrow = p.pos + (size_t)(1 + pp) * p.N;
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + lr;
+            for (int j = 0; j < JT; ++j) {
+                const int col = n0 + wn * WCOLS + j * 32 + lr;
                 if (NGUARD && col >= p.N)
                     continue;
                 float v = acc[i][j][r];
@@ -225,20 +284,38 @@ __global__ void cls_rows_kernel(const float *cls, const float *pos, float *token
     tokens[(size_t)b * tokens_per_image * E + e] = cls[e] + pos[e];
 }
 
-template <int AMODE, int EPI, bool NGUARD>
-int launch(hipStream_t st, const GemmParams &p)
+template <int AMODE, int EPI, bool NGUARD, int NW>
+int launch_nw(hipStream_t st, const GemmParams &p)
 {
     static bool attr_set = false; /* per instantiation; benign race (idempotent) */
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<AMODE, EPI, NGUARD>,
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<AMODE, EPI, NGUARD, NW>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         attr_set = true;
     }
     const int nwg = p.mtiles * p.ntiles;
-    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, NGUARD>), dim3(nwg), dim3(NTHREADS), LDS_BYTES,
+    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, NGUARD, NW>), dim3(nwg), dim3(64 * NW), LDS_BYTES,
                        st, p);
     VH_LAUNCH_CHECK("gemm_f32_kernel");
     return 0;
+}
+
+/* Waves per workgroup: 8 unless VIT_HIP_GEMM_NW=4 (tuning knob; results are identical). */
+int gemm_waves()
+{
+    static int nw = 0;
+    if (nw == 0) {
+        const char *env = getenv("VIT_HIP_GEMM_NW");
+        nw = (env && env[0] == '4') ? 4 : 8;
+    }
+    return nw;
+}
+
+template <int AMODE, int EPI, bool NGUARD>
+int launch(hipStream_t st, const GemmParams &p)
+{
+    return gemm_waves() == 4 ? launch_nw<AMODE, EPI, NGUARD, 4>(st, p)
+                             : launch_nw<AMODE, EPI, NGUARD, 8>(st, p);
 }
 
 } // namespace
