@@ -97,29 +97,31 @@ def main() -> None:
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (0 = auto)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
 
-    dist = None
-    torch = None
-    if world > 1:
-        import torch  # before the library: one HIP runtime per process (binding.lib())
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
     import __graft_entry__ as graft
+    comm = None
+    torch = None
+    if world_env > 1 or os.environ.get("VIT_DIST_FORCE", "0") == "1":
+        import torch  # before the library: one HIP runtime per process (binding.lib())
+        pkg = graft.load_package()
+        from vit_with_opencl_amd.host.dist import Comm
+        comm = Comm()   # backend nccl (= RCCL); VIT_DIST_BACKEND=gloo only for single-GPU rehearsal
     pkg = graft.load_package()
+    rank = comm.rank if comm else 0
+    world = comm.world if comm else 1
+    # one GPU per rank; VIT_BENCH_DEVICE pins every rank to one card for a gloo rehearsal
+    device = int(os.environ.get("VIT_BENCH_DEVICE", comm.local_rank if comm else 0))
+
     cfg = pkg.preset("vit_b_16")
     tokens = pkg.binding.tokens(cfg)
     B, NC = args.batch, cfg.num_classes
 
     weights = pkg.synth_weights(cfg, 0)
-    model = pkg.ViTHip(cfg, weights, device=local_rank, max_batch=B)
+    model = pkg.ViTHip(cfg, weights, device=device, max_batch=B)
     L = pkg.lib()
 
     # Synthetic batch, distinct images per rank: global image index = rank*B + i.  Generated
@@ -132,29 +134,32 @@ def main() -> None:
         pkg.binding.check(L.vh_h2d(d_images.ptr.value + lo * per * 4, chunk.ctypes.data, n * per * 4, None), "vh_h2d")
         pkg.binding.check(L.vh_device_sync(), "sync")
 
-    if world > 1:
+    d_probs = pkg.DeviceBuffer(B * NC)
+    use_rccl = comm is not None and comm.backend == "nccl"
+    if use_rccl:
+        # logits land in a torch tensor so RCCL can gather them; launch on torch's stream
         t_logits = torch.empty(B, NC, device="cuda", dtype=torch.float32)
-        t_gather = [torch.empty(B, NC, device="cuda", dtype=torch.float32) for _ in range(world)] if rank == 0 else None
         d_logits_ptr = t_logits.data_ptr()
-        stream = torch.cuda.current_stream().cuda_stream   # launch on torch's stream: RCCL orders after it
-        d_probs = pkg.DeviceBuffer(B * NC)
+        stream = torch.cuda.current_stream().cuda_stream
     else:
         d_logits = pkg.DeviceBuffer(B * NC)
         d_logits_ptr = d_logits.ptr
-        d_probs = pkg.DeviceBuffer(B * NC)
         stream = model.stream
+    gathered = [None]
 
     def step():
         model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
-        if world > 1:
-            dist.gather(t_logits, t_gather, dst=0)
+        if use_rccl:
+            gathered[0] = comm.gather_rows(t_logits)
+        elif comm is not None:   # gloo rehearsal: through host memory
+            gathered[0] = comm.gather_rows(torch.from_numpy(d_logits.to_numpy((B, NC))))
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
+        if use_rccl:
             torch.cuda.synchronize()
-        else:
-            pkg.binding.check(L.vh_device_sync(), "sync")
+        pkg.binding.check(L.vh_device_sync(), "sync")
 
     for _ in range(args.warmup):
         step()
@@ -169,10 +174,8 @@ def main() -> None:
     prof = model.profile_read()
     model.profile_enable(0)
 
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.max_over_ranks(elapsed)
 
     if rank == 0:
         flops = model_flops(cfg, tokens)
@@ -206,9 +209,9 @@ def main() -> None:
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
 
         # sanity of what was computed + parity against the CPU path in the same run
-        logits_dev = (t_gather[0] if world > 1 else None)
-        if world > 1:
-            logits0 = logits_dev[0].cpu().numpy()
+        if comm is not None:
+            logits0 = gathered[0][0][0].cpu().numpy()
+            assert len(gathered[0]) == world and all(t.shape == (B, NC) for t in gathered[0])
         else:
             logits0 = d_logits.to_numpy((B, NC))[0]
         probs0 = d_probs.to_numpy((B, NC))[0]
@@ -237,9 +240,8 @@ def main() -> None:
         print(json.dumps(out), flush=True)
 
     model.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
 
 
 if __name__ == "__main__":
