@@ -20,7 +20,7 @@
  *    next product O^T = V^T P^T, whose A operand V[key][d] is read from LDS
  *    with the lane on d.
  *  - Numerics follow the scalar loop: scores scaled after the dot product,
- *    max-subtracted expf, normalised by division before the P.V product.
+ *    max-subtracted exp, normalised before the P.V product.
  *
  * Input rows are the fused projection output [Q(E) | K(E) | V(E)]; output is
  * [n_images*T][E] with heads concatenated (ViT_seq.c:252-258).
@@ -70,6 +70,17 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
 
     __syncthreads();
 
+    /* Waves w and w+4 share a SIMD.  Running in lockstep they would both want the
+     * matrix pipe (QK^T, PV) and then both the VALU (softmax).  Holding the second
+     * wave of each SIMD back by about one MFMA phase makes the phases complementary:
+     * one wave's softmax runs under the other's MFMAs.  While it sleeps its partner
+     * has the pipe to itself, so nothing is lost.  Speed only; results are unchanged. */
+    if (NKT > 4 && __builtin_amdgcn_readfirstlane(wave) >= 4) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)(NKT * 32 * 64))
+            __builtin_amdgcn_s_sleep(32);
+    }
+
     /* S^T tiles: rows = keys of tile j, column = this lane's query. */
     f32x16 s[NKT];
 #pragma unroll
@@ -86,15 +97,21 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
         }
     }
 
-    /* Row softmax over keys (ViT_seq.c:211, :216-234). */
-    const float scale = sqrtf((float)HD);
+    /* Row softmax over keys (ViT_seq.c:211, :216-234): scale after the dot product
+     * (division by sqrt(64) = 8 is exactly a multiplication by 0.125), subtract the row
+     * maximum, exponentiate, normalise.  exp() is exp2 on a two-term product
+     * x*log2(e) = t + r (t rounded, r the exact remainder plus the low part of log2 e),
+     * exp2(t) * (1 + r ln 2): ~1 ulp like libm expf at a third of the instructions;
+     * the normalisation multiplies by one correctly rounded reciprocal per row instead
+     * of dividing 197 times (<= 1 ulp per probability). */
+    const float inv_scale = 1.0f / sqrtf((float)HD);
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NKT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v = key < T ? s[j][r] / scale : -INFINITY;
+            const float v = key < T ? s[j][r] * inv_scale : -INFINITY;
             s[j][r] = v;
             mx = fmaxf(mx, v);
         }
@@ -104,16 +121,23 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
     for (int j = 0; j < NKT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = expf(s[j][r] - mx);
+            const int key = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float x = fmaxf(s[j][r] - mx, -120.0f);                    /* padding is -inf */
+            const float t = x * 1.44269502162933349609375f;                 /* fp32(log2 e) */
+            const float rem = __builtin_fmaf(x, 1.44269502162933349609375f, -t) +
+                              x * 1.925963033500011e-8f;                       /* log2 e - fp32(log2 e) */
+            const float e2 = __builtin_amdgcn_exp2f(t);
+            const float e = key < T ? __builtin_fmaf(e2, rem * 0.693147182464599609375f, e2) : 0.0f;
             s[j][r] = e;
             sum += e;
         }
     sum += __shfl_xor(sum, 32);
+    const float inv_sum = 1.0f / sum;
 #pragma unroll
     for (int j = 0; j < NKT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            s[j][r] = s[j][r] / sum;
+            s[j][r] = s[j][r] * inv_sum;
 
     /* O^T = V^T P^T: rows = d (two 32-wide tiles), column = this lane's query. */
     f32x16 o[2];
