@@ -13,20 +13,24 @@
  *  - v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit a k-ordered
  *    fmaf chain, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak.  There is no
  *    TF32-like shortcut on gfx950, so this is the fp32 roofline.
- *  - 128x128x32 block tile, 256 threads = 4 waves (2x2), each wave a 64x64
- *    output tile = 2x2 MFMA tiles (64 accumulator VGPRs).  Both operands are
- *    K-contiguous ("NT" GEMM), so A and W use the same LDS image: rows padded
- *    to 36 floats (144 B), which makes every ds_read_b128 fragment read
- *    conflict-free (16 rows -> 16 distinct 16-B slots of the 256-B bank row).
+ *  - Block tiles of BM x BN x 32 (template: 128x128 ... 256x256) cut into WM x WN
+ *    waves, each wave IT x JT MFMA tiles of 32x32.  Both operands are K-contiguous
+ *    ("NT" GEMM), so A and W use the same LDS image: 128-byte rows whose 16-byte
+ *    chunks are XOR-swizzled (chunk c of row r at c ^ ((r >> 1) & 7)), which makes
+ *    every ds_read_b128 fragment read conflict-free (the 16 rows of a lane group
+ *    hit 16 distinct 16-B slots of the 256-B bank row).
  *  - One ds_read_b128 per 32-row fragment yields four k-pairs: lane l holds
  *    k = 8*kk + 4*(l>>5) + e in register e, and MFMA step e contracts the
  *    pair {e, 4+e}; A and W use the same permutation, so only the summation
  *    order inside an 8-wide k group differs from the scalar loop.
- *  - Global->register->LDS double buffering, issue-early / write-late: K-tile
- *    t+2's 8 x 16-B loads per thread are issued right after K-tile t+1 has been
- *    written to the free LDS stage at the START of step t, so a load has a whole
- *    step (4096-8192 cycles of MFMA) to land and the LDS writes overlap the
- *    MFMAs; one barrier per K-tile, 2 blocks (8 waves) per CU.
+ *  - K-tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA): no staging
+ *    VGPRs, no ds_write instructions.  An LDS-DMA wave-instruction writes 64 x 16 B
+ *    linearly (wave-uniform base + lane*16), so rows cannot be padded; the swizzle
+ *    is applied to the per-lane SOURCE address and, identically, to the reads.
+ *    Two LDS stages: step t issues the DMA of K-tile t+1 into the stage read in
+ *    step t-1 right after the barrier, computes K-tile t, and __syncthreads()
+ *    (vmcnt(0) + barrier) publishes K-tile t+1 -- a load has a whole step of MFMAs
+ *    to land.
  *  - The accumulator starts at the bias, like the scalar loop it replaces
  *    (`sum = bias[o]`, ViT_seq.c:301), and the residual is added to the
  *    finished sum (ViT_seq.c:350,362).
@@ -41,13 +45,31 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDT = BK + 4;          /* padded LDS row length in floats */
-constexpr int TILE_F = BM * LDT;     /* floats per operand tile per stage */
-constexpr size_t LDS_BYTES = sizeof(float) * 4 * TILE_F; /* 2 stages x (A,W) */
+constexpr int BK = 32;
 
 enum { A_ROWS = 0, A_PATCH = 1 };
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+/* Block-tile configuration: BM x BN outputs, WM x WN waves. */
+template <int BM_, int BN_, int WM_, int WN_>
+struct Tile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int NW = WM * WN;               /* waves per workgroup */
+    static constexpr int NT = 64 * NW;               /* threads */
+    static constexpr int IT = BM / WM / 32;          /* 32-row MFMA tiles per wave */
+    static constexpr int JT = BN / WN / 32;          /* 32-col MFMA tiles per wave */
+    static constexpr int CHA = BM / 8 / NW;          /* 8-row DMA pieces per wave, A */
+    static constexpr int CHW = BN / 8 / NW;          /* 8-row DMA pieces per wave, W */
+    static constexpr int STAGE_F = (BM + BN) * BK;   /* floats per LDS stage */
+    static constexpr size_t LDS = sizeof(float) * 2 * STAGE_F;
+    static constexpr int WG_PER_CU = (2 * LDS <= 160 * 1024) ? 2 : 1;
+    static constexpr int MIN_WAVES_PER_SIMD = WG_PER_CU * NW / 4;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "DMA pieces must divide evenly over waves");
+    static_assert(IT >= 1 && JT >= 1 && LDS <= 160 * 1024, "tile does not fit");
+};
 
 struct GemmParams {
     const float *A, *W, *bias, *R, *pos;
@@ -67,56 +89,39 @@ __device__ __forceinline__ int xcd_tile(int bid, int nwg)
     return start + idx;
 }
 
-/* Branch-free fp32 erf for the fc1 epilogue.  The scalar loop calls libm erff
- * (ViT_seq.c:285); a device libm erff is two divergent branches of ~50 VALU
- * instructions each, which made the GELU epilogue a third of the fc1 kernel.  Here:
- *   |x| <  0.921875 : x + x*P(x^2)
- *   otherwise       : sign(x) * (1 - exp(-t*Q(t))), t = min(|x|, 4)
- * with P, Q least-squares fits on Chebyshev nodes (tools/fit_erf.py), both evaluated
- * unconditionally and selected.  Measured there: max |this - erf| = 8.1e-8 and
- * max |this - glibc erff| = 6.0e-8 (1 ulp at 0.5..1), glibc itself being 4.5e-8 off. */
-__device__ __forceinline__ float erf_f32(float x)
-{
-    const float t = fminf(fabsf(x), 4.0f);
-    const float s = x * x;
-    float p = 8.392696327e-05f;
-    p = __builtin_fmaf(p, s, -8.148506167e-04f);
-    p = __builtin_fmaf(p, s, 5.201591644e-03f);
-    p = __builtin_fmaf(p, s, -2.685964666e-02f);
-    p = __builtin_fmaf(p, s, 1.128370017e-01f);
-    p = __builtin_fmaf(p, s, -3.761263490e-01f);
-    p = __builtin_fmaf(p, s, 1.283791661e-01f);
-    const float small = __builtin_fmaf(p, x, x);
-    float q = -9.613538623e-07f;
-    q = __builtin_fmaf(q, t, 3.291785833e-05f);
-    q = __builtin_fmaf(q, t, -4.882355570e-04f);
-    q = __builtin_fmaf(q, t, 4.262940958e-03f);
-    q = __builtin_fmaf(q, t, -2.504872903e-02f);
-    q = __builtin_fmaf(q, t, 1.077397019e-01f);
-    q = __builtin_fmaf(q, t, 6.342266202e-01f);
-    q = __builtin_fmaf(q, t, 1.128881097e+00f);
-    const float large = copysignf(1.0f - __expf(-t * q), x);
-    return fabsf(x) < 0.921875f ? small : large;
-}
-
+/* GELU for the fc1 epilogue: 0.5*x*(1+erf(x/sqrt(2))), ViT_seq.c:285 / ll.cl:4.
+ * The scalar loop calls libm erff; a device libm erff is two divergent branches of
+ * ~50 VALU instructions each, which made this epilogue a third of the fc1 kernel
+ * (42 us per 128x128 tile).  GELU only needs erf to ABSOLUTE accuracy (it forms
+ * 1 + erf), so one branch-free form serves every x:
+ *     erf(a) = sign(a) * (1 - 2^(-t*S(t))),  t = min(|a|, 4),  S(t) = -log2(erfc(t))/t
+ * with S a degree-10 least-squares fit on Chebyshev nodes (tools/fit_gelu.py):
+ * max |erf - exact| = 8.2e-8, max |gelu - scalar fp32 formula with glibc erff| = 2.4e-7
+ * (half an ulp at |x| = 8; that scalar formula is itself 4.5e-7 from exact).
+ * The division by sqrt(2) is a multiplication by its fp32 reciprocal. */
 __device__ __forceinline__ float gelu_exact(float x)
 {
-    /* 0.5*x*(1+erf(x/sqrt(2))), ViT_seq.c:285 / ll.cl:4; the division by sqrt(2) is a
-     * multiplication by its fp32 reciprocal (<= 1 ulp on the erf argument). */
-    return 0.5f * x * (1.0f + erf_f32(x * 0.70710678118654752f));
+    const float a = x * 0.70710678118654752f;
+    const float t = fminf(fabsf(a), 4.0f);
+    float s = -1.434945176e-07f;
+    s = __builtin_fmaf(s, t, 3.633770575e-06f);
+    s = __builtin_fmaf(s, t, -4.095854820e-05f);
+    s = __builtin_fmaf(s, t, 2.688577224e-04f);
+    s = __builtin_fmaf(s, t, -1.106124371e-03f);
+    s = __builtin_fmaf(s, t, 2.616208047e-03f);
+    s = __builtin_fmaf(s, t, -3.566097876e-04f);
+    s = __builtin_fmaf(s, t, -2.759680524e-02f);
+    s = __builtin_fmaf(s, t, 1.482741833e-01f);
+    s = __builtin_fmaf(s, t, 9.184474349e-01f);
+    s = __builtin_fmaf(s, t, 1.627907038e+00f);
+    const float erf_a = copysignf(1.0f - __builtin_amdgcn_exp2f(-(t * s)), a);
+    return 0.5f * x * (1.0f + erf_a);
 }
 
-/* NW = waves per workgroup: 4 (2x2 waves, 64x64 each) or 8 (2x4 waves, 64x32 each).
- * Two workgroups are resident per CU either way (LDS), i.e. 2 or 4 waves per SIMD. */
-template <int AMODE, int EPI, bool NGUARD, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_f32_kernel(const GemmParams p)
+template <class T, int AMODE, int EPI, bool NGUARD>
+__global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(const GemmParams p)
 {
-    constexpr int NT = 64 * NW;          /* threads */
-    constexpr int WN = NW / 2;           /* waves along N */
-    constexpr int WCOLS = BN / WN;       /* columns per wave: 64 or 32 */
-    constexpr int JT = WCOLS / 32;       /* 32-wide MFMA column tiles per wave */
-    constexpr int RP = NT / 8;           /* rows staged per pass (8 x 16-B chunks per row) */
-    constexpr int CH = BM / RP;          /* staged chunks per thread per operand */
+    constexpr int BM = T::BM, BN = T::BN, IT = T::IT, JT = T::JT;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -124,17 +129,22 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_f32_kernel(const GemmPar
     const int m0 = (tile / p.ntiles) * BM;
     const int n0 = (tile % p.ntiles) * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
-    const int ld_row = tid >> 3, ld_kc = (tid & 7) * 4; /* staging: rows ld_row+RP*i, floats ld_kc..+3 */
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / T::WN, wn = wave % T::WN, lr = lane & 31, lh = lane >> 5;
 
-    /* Per-thread source rows for the staged chunks of each operand. */
-    const float *a_src[CH], *w_src[CH];
+    /* DMA piece q covers tile rows 8q..8q+7; this lane fills physical chunk (lane & 7)
+     * of row 8q + (lane >> 3) with logical chunk phys ^ swizzle(row). */
+    const float *a_src[T::CHA], *w_src[T::CHW];
+    int a_k[T::CHA];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        int m = min(m0 + ld_row + RP * i, p.M - 1);
+    for (int i = 0; i < T::CHA; ++i) {
+        const int r = 8 * (wave * T::CHA + i) + (lane >> 3);
+        const int kc = 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        a_k[i] = kc;
+        const int m = min(m0 + r, p.M - 1);
         if (AMODE == A_ROWS) {
-            a_src[i] = p.A + (size_t)m * p.K + ld_kc;
+            a_src[i] = p.A + (size_t)m * p.K + kc;
         } else {
             const int np = p.grid * p.grid;
             const int b = m / np, pp = m - b * np;
@@ -142,98 +152,95 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_f32_kernel(const GemmPar
             a_src[i] = p.A + ((size_t)b * p.chans * p.img + (size_t)oh * p.patch) * p.img +
                        (size_t)ow * p.patch;
         }
-        int n = n0 + ld_row + RP * i;
+    }
+#pragma unroll
+    for (int i = 0; i < T::CHW; ++i) {
+        const int r = 8 * (wave * T::CHW + i) + (lane >> 3);
+        const int kc = 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        int n = n0 + r;
         if (NGUARD)
             n = min(n, p.N - 1);
-        w_src[i] = p.W + (size_t)n * p.K + ld_kc;
+        w_src[i] = p.W + (size_t)n * p.K + kc;
     }
 
-    f32x4 ra[CH], rw[CH];
-    auto gload = [&](int k0) {
+    auto dma = [&](int stage, int k0) {
+        float *As = smem + stage * T::STAGE_F, *Ws = As + BM * BK;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
+        for (int i = 0; i < T::CHA; ++i) {
+            const float *ap;
             if (AMODE == A_ROWS) {
-                ra[i] = *reinterpret_cast<const f32x4 *>(a_src[i] + k0);
+                ap = a_src[i] + k0;
             } else {
                 /* im2row on load: k = (ic, kh, kw); 4 consecutive kw are contiguous. */
-                const int k = k0 + ld_kc, pp2 = p.patch * p.patch;
+                const int k = k0 + a_k[i], pp2 = p.patch * p.patch;
                 const int ic = k / pp2, rem = k - ic * pp2;
                 const int kh = rem / p.patch, kw = rem - kh * p.patch;
-                ra[i] = *reinterpret_cast<const f32x4 *>(
-                    a_src[i] + ((size_t)ic * p.img + kh) * p.img + kw);
+                ap = a_src[i] + ((size_t)ic * p.img + kh) * p.img + kw;
             }
-            rw[i] = *reinterpret_cast<const f32x4 *>(w_src[i] + k0);
+            __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(As + (wave * T::CHA + i) * 8 * BK), 16, 0, 0);
         }
-    };
-    auto lstore = [&](int stage) {
-        float *As = smem + stage * 2 * TILE_F, *Ws = As + TILE_F;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            *reinterpret_cast<f32x4 *>(As + (ld_row + RP * i) * LDT + ld_kc) = ra[i];
-            *reinterpret_cast<f32x4 *>(Ws + (ld_row + RP * i) * LDT + ld_kc) = rw[i];
-        }
+        for (int i = 0; i < T::CHW; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + k0),
+                                             (lptr_t)(Ws + (wave * T::CHW + i) * 8 * BK), 16, 0, 0);
     };
 
-    /* Accumulators start at the bias (column = lane & 31 of each 32-wide tile). */
-    f32x16 acc[2][JT];
+    /* Accumulators start at the bias (column = lane & 31 of each 32-wide tile), like
+     * the scalar loop (`sum = bias[o]`, ViT_seq.c:301). */
+    f32x16 acc[IT][JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-        int col = n0 + wn * WCOLS + j * 32 + lr;
+        int col = n0 + wn * (32 * JT) + j * 32 + lr;
         if (NGUARD)
             col = min(col, p.N - 1);
         const float bv = p.bias[col];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < IT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[i][j][r] = bv;
     }
 
-    /* K loop.  Invariant at the top of step kt: LDS stage kt&1 holds K-tile kt
-     * (visible to all waves), the staging registers hold (or are receiving) K-tile
-     * kt+1.  The other stage was last read in step kt-1 and every wave has passed
-     * the barrier since, so K-tile kt+1 is written there right away and the loads for
-     * K-tile kt+2 are re-issued into the same registers: the ds_writes and the
-     * global loads then sit among this step's MFMAs instead of in an MFMA-free
-     * tail, and the only exposed latency per step is barrier + first fragment read. */
-    auto compute_kk = [&](const float *a_base, const float *w_base, int kk) {
-        f32x4 a[2], b[JT];
+    /* Fragment rows wm*32*IT + i*32 + lr (and the W analogue) all have
+     * (row >> 1) & 7 == (lr >> 1) & 7, so the read swizzle is one per-lane constant.
+     * One ds_read_b128 gives k = 8*kk + 4*lh + e in element e; MFMA step e contracts
+     * the pair {e, 4 + e} of that 8-wide k group (same permutation for A and W). */
+    const int swz = (lr >> 1) & 7;
+    int koff[BK / 8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            a[i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDT + kk * 8);
+    for (int kk = 0; kk < BK / 8; ++kk)
+        koff[kk] = 4 * ((2 * kk + lh) ^ swz);
+
+    auto compute_kk = [&](const float *a_base, const float *w_base, int kk) {
+        f32x4 a[IT], b[JT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+            a[i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * BK + koff[kk]);
 #pragma unroll
         for (int j = 0; j < JT; ++j)
-            b[j] = *reinterpret_cast<const f32x4 *>(w_base + j * 32 * LDT + kk * 8);
+            b[j] = *reinterpret_cast<const f32x4 *>(w_base + j * 32 * BK + koff[kk]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < IT; ++i)
 #pragma unroll
                 for (int j = 0; j < JT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     };
 
     const int nk = p.K / BK;
-    gload(0);
-    lstore(0);
-    if (nk > 1)
-        gload(BK);
+    dma(0, 0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const float *As = smem + cur * 2 * TILE_F, *Ws = As + TILE_F;
-        const float *a_base = As + (wm * 64 + lr) * LDT + lh * 4;
-        const float *w_base = Ws + (wn * WCOLS + lr) * LDT + lh * 4;
-
-        compute_kk(a_base, w_base, 0);
-        if (kt + 1 < nk) {
-            lstore(cur ^ 1);
-            if (kt + 2 < nk)
-                gload((kt + 2) * BK);
-        }
+        if (kt + 1 < nk)
+            dma(cur ^ 1, (kt + 1) * BK);
+        const float *As = smem + cur * T::STAGE_F, *Ws = As + BM * BK;
+        const float *a_base = As + (wm * 32 * IT + lr) * BK;
+        const float *w_base = Ws + (wn * 32 * JT + lr) * BK;
 #pragma unroll
-        for (int kk = 1; kk < BK / 8; ++kk)
+        for (int kk = 0; kk < BK / 8; ++kk)
             compute_kk(a_base, w_base, kk);
         __syncthreads();
     }
@@ -241,10 +248,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_f32_kernel(const GemmPar
     /* Epilogue.  C/D map of the 32x32 tile: col = lane & 31,
      * row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5). */
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < IT; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int row = m0 + wm * 32 * IT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (row >= p.M)
                 continue;
             size_t orow = (size_t)row;
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_f32_kernel(const GemmPar
             }
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                const int col = n0 + wn * WCOLS + j * 32 + lr;
+                const int col = n0 + wn * 32 * JT + j * 32 + lr;
                 if (NGUARD && col >= p.N)
                     continue;
                 float v = acc[i][j][r];
@@ -284,38 +291,60 @@ __global__ void cls_rows_kernel(const float *cls, const float *pos, float *token
     tokens[(size_t)b * tokens_per_image * E + e] = cls[e] + pos[e];
 }
 
-template <int AMODE, int EPI, bool NGUARD, int NW>
-int launch_nw(hipStream_t st, const GemmParams &p)
+template <class T, int AMODE, int EPI, bool NGUARD>
+int launch_tile(hipStream_t st, GemmParams p)
 {
     static bool attr_set = false; /* per instantiation; benign race (idempotent) */
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<AMODE, EPI, NGUARD, NW>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<T, AMODE, EPI, NGUARD>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS));
         attr_set = true;
     }
-    const int nwg = p.mtiles * p.ntiles;
-    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, NGUARD, NW>), dim3(nwg), dim3(64 * NW), LDS_BYTES,
-                       st, p);
+    p.mtiles = (p.M + T::BM - 1) / T::BM;
+    p.ntiles = (p.N + T::BN - 1) / T::BN;
+    hipLaunchKernelGGL((gemm_f32_kernel<T, AMODE, EPI, NGUARD>), dim3(p.mtiles * p.ntiles), dim3(T::NT),
+                       T::LDS, st, p);
     VH_LAUNCH_CHECK("gemm_f32_kernel");
     return 0;
 }
 
-/* Waves per workgroup: 8 unless VIT_HIP_GEMM_NW=4 (tuning knob; results are identical). */
-int gemm_waves()
+/* Tile configurations.  VIT_HIP_GEMM_CFG=<id> overrides the per-shape choice (tuning
+ * knob; every configuration computes the same k order, so results are identical). */
+using Tile0 = Tile<128, 128, 2, 4>; /*  8 waves of 64x32, 2 workgroups per CU */
+using Tile1 = Tile<128, 128, 2, 2>; /*  4 waves of 64x64, 2 workgroups per CU */
+using Tile2 = Tile<256, 128, 4, 2>; /*  8 waves of 64x64, 1 workgroup per CU  */
+using Tile3 = Tile<256, 256, 2, 4>; /*  8 waves of 128x64                      */
+using Tile4 = Tile<256, 256, 4, 4>; /* 16 waves of 64x64                       */
+using Tile5 = Tile<256, 128, 4, 4>; /* 16 waves of 64x32                       */
+using Tile6 = Tile<128, 256, 2, 4>; /*  8 waves of 64x64                       */
+
+int cfg_override()
 {
-    static int nw = 0;
-    if (nw == 0) {
-        const char *env = getenv("VIT_HIP_GEMM_NW");
-        nw = (env && env[0] == '4') ? 4 : 8;
+    static int v = -2;
+    if (v == -2) {
+        const char *env = getenv("VIT_HIP_GEMM_CFG");
+        v = (env && env[0] >= '0' && env[0] <= '6') ? env[0] - '0' : -1;
     }
-    return nw;
+    return v;
 }
 
-template <int AMODE, int EPI, bool NGUARD>
-int launch(hipStream_t st, const GemmParams &p)
+template <int AMODE, int EPI>
+int launch(hipStream_t st, const GemmParams &p, int default_cfg)
 {
-    return gemm_waves() == 4 ? launch_nw<AMODE, EPI, NGUARD, 4>(st, p)
-                             : launch_nw<AMODE, EPI, NGUARD, 8>(st, p);
+    if (p.N % 128 != 0)                      /* ragged N: only the guarded 128x128 tile */
+        return launch_tile<Tile0, AMODE, EPI, true>(st, p);
+    int cfg = cfg_override() >= 0 ? cfg_override() : default_cfg;
+    if ((cfg == 3 || cfg == 4 || cfg == 6) && p.N % 256 != 0)
+        cfg = 2;
+    switch (cfg) {
+    case 1: return launch_tile<Tile1, AMODE, EPI, false>(st, p);
+    case 2: return launch_tile<Tile2, AMODE, EPI, false>(st, p);
+    case 3: return launch_tile<Tile3, AMODE, EPI, false>(st, p);
+    case 4: return launch_tile<Tile4, AMODE, EPI, false>(st, p);
+    case 5: return launch_tile<Tile5, AMODE, EPI, false>(st, p);
+    case 6: return launch_tile<Tile6, AMODE, EPI, false>(st, p);
+    default: return launch_tile<Tile0, AMODE, EPI, false>(st, p);
+    }
 }
 
 } // namespace
@@ -336,15 +365,16 @@ extern "C" int vh_launch_linear(vh_stream_t s, float *output, const float *weigh
     GemmParams p = {};
     p.A = input; p.W = weight; p.bias = bias; p.R = residual; p.C = output;
     p.M = rowA; p.N = colB; p.K = colA;
-    p.mtiles = (rowA + BM - 1) / BM;
-    p.ntiles = (colB + BN - 1) / BN;
     hipStream_t st = (hipStream_t)s;
-    const bool nguard = (colB % BN) != 0;
+    /* Tile choice per shape, measured on ViT-B/16 at M = 100 864 (profiles/): wide
+     * outputs amortise operand traffic best with 256x256 / 16 waves; the N = 768
+     * projections prefer 128x128 tiles (more workgroups per round, two per CU). */
+    const bool wide = colB % 256 == 0 && colB >= 1536 && rowA >= 4096;
     if (doGelu)
-        return nguard ? launch<A_ROWS, EPI_GELU, true>(st, p) : launch<A_ROWS, EPI_GELU, false>(st, p);
+        return launch<A_ROWS, EPI_GELU>(st, p, wide ? 4 : 0);
     if (residual)
-        return nguard ? launch<A_ROWS, EPI_RESID, true>(st, p) : launch<A_ROWS, EPI_RESID, false>(st, p);
-    return nguard ? launch<A_ROWS, EPI_NONE, true>(st, p) : launch<A_ROWS, EPI_NONE, false>(st, p);
+        return launch<A_ROWS, EPI_RESID>(st, p, colA >= 2048 ? 1 : 0);
+    return launch<A_ROWS, EPI_NONE>(st, p, wide ? 4 : 0);
 }
 
 extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const float *conv_w,
@@ -366,8 +396,6 @@ extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const f
     GemmParams p = {};
     p.A = images; p.W = conv_w; p.bias = conv_b; p.pos = pos_embed; p.C = tokens;
     p.M = n_images * grid * grid; p.N = embed_dim; p.K = K;
-    p.mtiles = (p.M + BM - 1) / BM;
-    p.ntiles = (p.N + BN - 1) / BN;
     p.img = img_size; p.patch = patch_size; p.chans = in_chans; p.grid = grid;
     p.tokens = grid * grid + 1;
     hipStream_t st = (hipStream_t)s;
@@ -376,7 +404,5 @@ extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const f
     hipLaunchKernelGGL(cls_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, st, cls_token,
                        pos_embed, tokens, n_images, p.tokens, embed_dim);
     VH_LAUNCH_CHECK("cls_rows_kernel");
-    if (embed_dim % BN != 0)
-        return launch<A_PATCH, EPI_PATCH, true>(st, p);
-    return launch<A_PATCH, EPI_PATCH, false>(st, p);
+    return launch<A_PATCH, EPI_PATCH>(st, p, (embed_dim % 256 == 0 && p.M >= 4096) ? 4 : 0);
 }
