@@ -244,3 +244,22 @@ def test_torch_interop_shares_one_hip_runtime(pkg, device, weights, golden_full)
     torch.cuda.synchronize()
     assert np.abs(logits.cpu().numpy() - golden_full["logits"][:2]).max() <= LOGIT_TOL
     m.close()
+
+
+def test_vit_l16_one_image_vs_oracle(pkg, device):
+    """BASELINE config 4 shape (ViT-L/16: E=1024, 16 heads, F=4096, 24 layers) through the
+    same kernels.  The reference has no code for this shape (ViT_seq.c:10-21 hard-codes
+    B/16), so the oracle here is the port with other loop bounds: "parity unpinned".
+    ~40 s of CPU for the one oracle image."""
+    from oracle.oracle import Oracle
+    orc = Oracle("vit_l_16")
+    cfg = pkg.preset("vit_l_16")
+    weights = pkg.synth_weights(cfg, 7)
+    imgs = pkg.synth_images(cfg, 3, 2)
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=2)
+    logits, probs = m.forward(imgs)
+    m.close()
+    want_logits, want_probs, _ = orc.forward(imgs[1], weights)
+    assert np.abs(logits[1] - want_logits).max() <= LOGIT_TOL
+    assert int(logits[1].argmax()) == int(want_logits.argmax())
+    assert np.abs(probs[1] - want_probs).max() <= 1e-6

@@ -6,21 +6,30 @@
  * from global memory and reduces through LDS trees.  CPU statement:
  * multihead_attn_seq, ViT_seq.c:192-262.
  *
- * Design (MI355X / CDNA4), one workgroup per (image, head), one wave per
- * 32-query tile (7 waves for T = 197):
- *  - K and V head slices ([T][64] each) are staged once into LDS (K rows padded
- *    to 68 floats so the ds_read_b128 fragment reads are conflict-free; V rows
- *    are read 32 consecutive floats per half-wave, conflict-free unpadded).
- *  - S^T = K Q^T on v_mfma_f32_32x32x2_f32: with the key index on the MFMA row
- *    and the query on the lane, each lane ends up holding, for ITS query
- *    (lane & 31), all keys of its half (lane >> 5) in registers: the row
- *    softmax is register-local plus one lane-half exchange.
- *  - The normalised P never leaves registers: an S^T accumulator register is
- *    exactly the B operand (k = key pair {klo, klo+4}, column = query) of the
- *    next product O^T = V^T P^T, whose A operand V[key][d] is read from LDS
- *    with the lane on d.
+ * Design (MI355X / CDNA4): a persistent grid of one workgroup per CU walks the
+ * (image, head) items; one wave per 32-query tile (7 waves for T = 197).
+ *  - K and V head slices ([T][64] fp32 = 50 KB each) live in three rotating LDS
+ *    buffers filled by LDS-DMA (global_load_lds_dwordx4, no staging registers, no
+ *    ds_write): while item n computes, V_n and K_{n+1} stream in; V_{n+1} reuses
+ *    K_n's buffer.  All HBM latency sits under the MFMAs of the current item.
+ *    Hand-offs: one s_barrier per item (buffers free / next K visible) and one LDS
+ *    arrival counter (every wave's share of V_n has landed) polled before P.V.
+ *  - K rows are 256 B = the LDS bank row, so the 16 lanes of a ds_read_b128 group
+ *    (16 different keys, same d chunk) would hit one slot; chunk c of row r is kept
+ *    at c ^ (r & 15) instead (applied to the DMA source address and to the reads).
+ *    V is read 32 consecutive floats per half-wave: conflict-free as is.
+ *  - S^T = K Q^T on v_mfma_f32_32x32x2_f32: with the key index on the MFMA row and
+ *    the query on the lane, each lane ends up holding, for ITS query (lane & 31),
+ *    all keys of its half (lane >> 5) in registers: the row softmax is register-local
+ *    plus one lane-half exchange.
+ *  - The normalised P never leaves registers: an S^T accumulator register is exactly
+ *    the B operand (k = key pair {klo, klo+4}, column = query) of the next product
+ *    O^T = V^T P^T, whose A operand V[key][d] is read from LDS with the lane on d.
+ *  - Waves w and w+4 share a SIMD; the second one is held back by about one MFMA
+ *    phase so that one wave's softmax (VALU) runs under the other's MFMAs.
  *  - Numerics follow the scalar loop: scores scaled after the dot product,
- *    max-subtracted exp, normalised before the P.V product.
+ *    max-subtracted exponential, normalised before the P.V product (see the softmax
+ *    comment for the rounding differences).
  *
  * Input rows are the fused projection output [Q(E) | K(E) | V(E)]; output is
  * [n_images*T][E] with heads concatenated (ViT_seq.c:252-258).
@@ -30,157 +39,257 @@
 
 namespace {
 
-constexpr int HD = 64;        /* head dim this kernel is specialised for */
-constexpr int KLD = HD + 4;   /* padded K row (floats) */
+constexpr int HD = 64;                    /* head dim this kernel is specialised for */
+constexpr int MAX_LDS = 160 * 1024;
+constexpr int MAX_ROWS = (MAX_LDS - 64) / (3 * HD * 4) / 8 * 8; /* rows per buffer with 3 buffers: 208 */
 
-template <int NKT> /* number of 32-wide key/query tiles: T <= 32*NKT */
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int NKT> /* number of 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT */
 __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__restrict__ qkv,
                                                                 float *__restrict__ out, int T,
-                                                                int E, int H)
+                                                                int E, int H, int n_items, int RB)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Ks = smem;                  /* [NKT*32][KLD] */
-    float *Vs = smem + NKT * 32 * KLD; /* [NKT*32][HD]  */
+    const int buf_f = RB * HD;                                          /* floats per buffer */
+    unsigned *v_ready = reinterpret_cast<unsigned *>(smem + 3 * buf_f); /* arrivals of V shares */
 
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const size_t ld = (size_t)3 * E;
-    const float *base = qkv + (size_t)b * T * ld + (size_t)h * HD;
+    const int pieces = RB / 4;                                          /* 1-KiB DMA pieces per buffer */
 
-    /* Stage K and V (zero rows beyond T so the padded products stay finite). */
-    for (int idx = tid; idx < NKT * 32 * (HD / 4); idx += 64 * NKT) {
-        const int row = idx >> 4, c4 = (idx & 15) * 4;
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-        if (row < T) {
-            kv = *reinterpret_cast<const f32x4 *>(base + row * ld + E + c4);
-            vv = *reinterpret_cast<const f32x4 *>(base + row * ld + 2 * E + c4);
+    /* One LDS-DMA piece = 4 rows x 256 B; lane l fills 16-byte chunk (l & 15) of row
+     * 4p + (l >> 4).  which: 1 = K (swizzled), 2 = V (linear). */
+    auto dma = [&](int item, int which, float *dst) {
+        const int b = item / H, h = item - b * H;
+        const float *base = qkv + (size_t)b * T * ld + (size_t)h * HD + (size_t)which * E;
+        for (int p = wave; p < pieces; p += NKT) {
+            const int r = 4 * p + (lane >> 4);
+            int c = lane & 15;
+            if (which == 1)
+                c ^= r & 15;
+            const float *src = base + (size_t)min(r, T - 1) * ld + 4 * c; /* rows >= T: finite duplicates */
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + p * 4 * HD), 16, 0, 0);
         }
-        *reinterpret_cast<f32x4 *>(Ks + row * KLD + c4) = kv;
-        *reinterpret_cast<f32x4 *>(Vs + row * HD + c4) = vv;
-    }
+    };
 
-    /* This lane's query row; d = 8c + 4*lh + e in element e of chunk c. */
+    /* Query fragments: lane's row q = 32*wave + (lane & 31); element e of chunk c is
+     * d = 8c + 4*(lane >> 5) + e.  They are loaded one item ahead (after P.V, when the
+     * P registers are dead) and waited for at the end-of-item barrier, so that no
+     * ordinary load is outstanding while the DMAs of an item are in flight -- the
+     * compiler would otherwise wait for everything (vmcnt(0)) at the fragments' first use. */
     const int q = wave * 32 + lr;
     const int qc = min(q, T - 1);
     f32x4 qf[HD / 8];
+    auto load_q = [&](int it) {
+        const int b = it / H, h = it - b * H;
+        const float *row = qkv + ((size_t)b * T + qc) * ld + (size_t)h * HD + 4 * lh;
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c)
-        qf[c] = *reinterpret_cast<const f32x4 *>(base + qc * ld + 8 * c + 4 * lh);
+        for (int c = 0; c < HD / 8; ++c)
+            qf[c] = *reinterpret_cast<const f32x4 *>(row + 8 * c);
+    };
 
-    __syncthreads();
-
-    /* Waves w and w+4 share a SIMD.  Running in lockstep they would both want the
-     * matrix pipe (QK^T, PV) and then both the VALU (softmax).  Holding the second
-     * wave of each SIMD back by about one MFMA phase makes the phases complementary:
-     * one wave's softmax runs under the other's MFMAs.  While it sleeps its partner
-     * has the pipe to itself, so nothing is lost.  Speed only; results are unchanged. */
-    if (NKT > 4 && __builtin_amdgcn_readfirstlane(wave) >= 4) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)(NKT * 32 * 64))
-            __builtin_amdgcn_s_sleep(32);
-    }
-
-    /* S^T tiles: rows = keys of tile j, column = this lane's query. */
-    f32x16 s[NKT];
-#pragma unroll
-    for (int j = 0; j < NKT; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            s[j][r] = 0.0f;
+    /* Per-lane LDS byte offsets (item-independent).  K fragment of key row r, d chunk
+     * (2c + lh): row r at r*256 B, chunk swizzled with r & 15.  V: lane reads
+     * V[key][lr] and V[key][32 + lr] with key = k0 + 4*lh + rr. */
+    int kofs[HD / 8], kofs_last[HD / 8];
+    {
+        const int rl = min(32 * (NKT - 1) + lr, RB - 1);
 #pragma unroll
         for (int c = 0; c < HD / 8; ++c) {
-            const f32x4 kf = *reinterpret_cast<const f32x4 *>(Ks + (32 * j + lr) * KLD + 8 * c + 4 * lh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[j], 0, 0, 0);
+            kofs[c] = lr * (HD * 4) + 16 * ((2 * c + lh) ^ (lr & 15));
+            kofs_last[c] = rl * (HD * 4) + 16 * ((2 * c + lh) ^ (rl & 15));
         }
     }
+    const int vofs = (4 * lh * HD + lr) * 4;
 
-    /* Row softmax over keys (ViT_seq.c:211, :216-234): scale after the dot product
-     * (division by sqrt(64) = 8 is exactly a multiplication by 0.125), subtract the row
-     * maximum, exponentiate, normalise.  exp() is exp2 on a two-term product
-     * x*log2(e) = t + r (t rounded, r the exact remainder plus the low part of log2 e),
-     * exp2(t) * (1 + r ln 2): ~1 ulp like libm expf at a third of the instructions;
-     * the normalisation multiplies by one correctly rounded reciprocal per row instead
-     * of dividing 197 times (<= 1 ulp per probability). */
-    const float inv_scale = 1.0f / sqrtf((float)HD);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < NKT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v = key < T ? s[j][r] * inv_scale : -INFINITY;
-            s[j][r] = v;
-            mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NKT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float x = fmaxf(s[j][r] - mx, -120.0f);                    /* padding is -inf */
-            const float t = x * 1.44269502162933349609375f;                 /* fp32(log2 e) */
-            const float rem = __builtin_fmaf(x, 1.44269502162933349609375f, -t) +
-                              x * 1.925963033500011e-8f;                       /* log2 e - fp32(log2 e) */
-            const float e2 = __builtin_amdgcn_exp2f(t);
-            const float e = key < T ? __builtin_fmaf(e2, rem * 0.693147182464599609375f, e2) : 0.0f;
-            s[j][r] = e;
-            sum += e;
-        }
-    sum += __shfl_xor(sum, 32);
-    const float inv_sum = 1.0f / sum;
-#pragma unroll
-    for (int j = 0; j < NKT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            s[j][r] = s[j][r] * inv_sum;
+    int item = blockIdx.x;
+    if (item >= n_items)
+        return;
+    if (tid == 0)
+        *v_ready = 0;
+    load_q(item);
+    dma(item, 1, smem); /* K of the first item into buffer 0 */
+    __syncthreads();    /* vmcnt(0) + barrier */
 
-    /* O^T = V^T P^T: rows = d (two 32-wide tiles), column = this lane's query. */
-    f32x16 o[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        o[0][r] = 0.0f;
-        o[1][r] = 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < NKT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v0 = Vs[key * HD + lr];
-            const float v1 = Vs[key * HD + 32 + lr];
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[j][r], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[j][r], o[1], 0, 0, 0);
+    unsigned n = 0;     /* local item counter: K in buffer (2n)%3, V in (2n+1)%3, free (2n+2)%3 */
+    for (; item < n_items; item += gridDim.x, ++n) {
+        /* Buffer roles of this item.  The byte offsets are made opaque so that the
+         * per-lane LDS addresses below are formed per item (one add each) instead of
+         * being hoisted out of the loop for all three buffers -- that hoisting costs
+         * well over a hundred VGPRs and spills. */
+        unsigned kb = ((2 * n) % 3) * buf_f * 4, vb = ((2 * n + 1) % 3) * buf_f * 4;
+        asm volatile("" : "+s"(kb), "+s"(vb));
+        const char *Kb = reinterpret_cast<const char *>(smem) + kb;
+        const char *Vb = reinterpret_cast<const char *>(smem) + vb;
+        float *Vs = smem + ((2 * n + 1) % 3) * buf_f;
+        float *Kn = smem + ((2 * n + 2) % 3) * buf_f;
+        const int b = item / H, h = item - b * H;
+        const int next = item + gridDim.x;
+
+        /* Both target buffers were released by the barrier that ended the previous item. */
+        dma(item, 2, Vs);
+        if (next < n_items)
+            dma(next, 1, Kn);
+
+        /* Second wave of each SIMD: post its V share first (waiting for the DMA is part
+         * of its hold-back), then sleep out the rest of one MFMA phase. */
+        const bool late = NKT > 4 && wave >= 4;
+        if (late) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_fetch_add(v_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)(NKT * 32 * 64))
+                __builtin_amdgcn_s_sleep(32);
         }
 
-    if (q < T) {
-        float *dst = out + ((size_t)b * T + q) * E + (size_t)h * HD + 4 * lh;
+        /* S^T tiles: rows = keys of tile j, column = this lane's query. */
+        f32x16 s[NKT];
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int j = 0; j < NKT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                s[j][r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < HD / 8; ++c) {
+                /* rows 32j + lr: lane offset + compile-time j*8 KiB; only the last tile can
+                 * run past the buffer and uses the clamped-row offsets */
+                const f32x4 kf = (j < NKT - 1)
+                    ? *reinterpret_cast<const f32x4 *>(Kb + kofs[c] + j * 32 * HD * 4)
+                    : *reinterpret_cast<const f32x4 *>(Kb + kofs_last[c]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[j], 0, 0, 0);
+            }
+        }
+
+        if (!late) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* issued a whole QK^T phase ago */
+            if (lane == 0)
+                __hip_atomic_fetch_add(v_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+
+        /* Row softmax over keys (ViT_seq.c:211, :216-234).  The scalar loop computes
+         * expf(score/sqrt(D) - max) / sum; here the scale (an exact power of two for
+         * D = 64), the max subtraction and the change of base are one fma per element,
+         *     e = 2^(s * c1 + c2),  c1 = log2(e)/sqrt(D),  c2 = -max * c1,
+         * followed by one multiplication with a correctly rounded reciprocal of the row
+         * sum.  The rounding of c2 is a common factor of the whole row and cancels in the
+         * normalisation; per element the result is within ~|x| * 6e-8 relative of the
+         * scalar value, far below the 2e-5 operator tolerance.  Keys >= T exist only in
+         * the last tile; they are set to -inf, which the fma carries to 2^-inf = 0. */
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * (NKT - 1) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            s[NKT - 1][r] = key < T ? s[NKT - 1][r] : -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mx = fmaxf(mx, s[j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float c1 = 1.44269504088896340736f / sqrtf((float)HD);
+        const float c2 = -mx * c1;
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][r], c1, c2));
+                s[j][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv_sum = 1.0f / sum;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                s[j][r] = s[j][r] * inv_sum;
+
+        /* All NKT shares of V_n landed?  (Arrivals were posted at least one MFMA phase
+         * ago; this poll normally passes at once.) */
+        const unsigned want = (unsigned)NKT * (n + 1);
+        while (__hip_atomic_load(v_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+            __builtin_amdgcn_s_sleep(1);
+
+        /* O^T = V^T P^T: rows = d (two 32-wide tiles), column = this lane's query.
+         * Register groups whose keys are all >= T carry P = 0 and are skipped. */
+        f32x16 o[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o[0][r] = 0.0f;
+            o[1][r] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(dst + dt * 32 + 8 * g) = v;
+                if (j == NKT - 1 && 32 * j + 8 * g >= T)
+                    continue;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = 4 * g + rr;
+                    /* keys k0 + rr + 4*lh with k0 = 32j + 8g < T: all 8 rows exist (RB = T up to 8) */
+                    const char *vp = Vb + vofs + (32 * j + 8 * g + rr) * (HD * 4);
+                    const float v0 = *reinterpret_cast<const float *>(vp);
+                    const float v1 = *reinterpret_cast<const float *>(vp + 32 * 4);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[j][r], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[j][r], o[1], 0, 0, 0);
+                }
             }
+
+        if (next < n_items) {
+            asm volatile("" ::: "memory"); /* not above the P.V reads: P's registers must be dead */
+            load_q(next);
+        }
+
+        if (q < T) {
+            float *dst = out + ((size_t)b * T + q) * E + (size_t)h * HD + 4 * lh;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(dst + dt * 32 + 8 * g) = v;
+                }
+        }
+
+        /* End of item: every wave is done with K_n and V_n (their buffers are free) and
+         * has waited for its share of K_{n+1}, which the barrier publishes. */
+        __syncthreads();
     }
 }
 
 template <int NKT>
 int launch(hipStream_t st, const float *qkv, float *out, int n_images, int T, int E, int H)
 {
-    const size_t lds = sizeof(float) * NKT * 32 * (KLD + HD);
+    const int RB = (T + 7) / 8 * 8; /* rows per buffer: whole 8-key register groups, whole 4-row DMA pieces */
+    const size_t lds = sizeof(float) * 3 * RB * HD + 64;
     static bool attr_set = false;
     if (!attr_set) {
         VH_TRY(hipFuncSetAttribute((const void *)attention_f32_kernel<NKT>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_f32_kernel<NKT>), dim3(n_images * H), dim3(64 * NKT), lds, st, qkv,
-                       out, T, E, H);
+    /* Persistent grid: one workgroup per CU (the three K/V buffers fill a CU's LDS),
+     * each walking (image, head) items blockIdx.x, blockIdx.x + grid, ... */
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        VH_TRY(hipGetDevice(&dev));
+        VH_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int n_items = n_images * H;
+    const int grid = n_items < num_cus ? n_items : num_cus;
+    hipLaunchKernelGGL((attention_f32_kernel<NKT>), dim3(grid), dim3(64 * NKT), lds, st, qkv, out, T, E,
+                       H, n_items, RB);
     VH_LAUNCH_CHECK("attention_f32_kernel");
     return 0;
 }
@@ -195,9 +304,9 @@ extern "C" int vh_launch_attention(vh_stream_t s, const float *qkv, float *outpu
     if (n_images <= 0 || tokens <= 0 || num_heads <= 0 || embed_dim != num_heads * HD)
         return vh_fail(1, "vh_launch_attention: needs head_dim == %d (embed=%d heads=%d)", HD,
                        embed_dim, num_heads);
-    if (tokens > 32 * 7)
-        return vh_fail(1, "vh_launch_attention: tokens=%d exceeds the %d this kernel holds in registers",
-                       tokens, 32 * 7);
+    if (tokens > MAX_ROWS)
+        return vh_fail(1, "vh_launch_attention: tokens=%d exceeds the %d whose three K/V buffers fit a CU's LDS",
+                       tokens, MAX_ROWS);
     hipStream_t st = (hipStream_t)s;
     switch ((tokens + 31) / 32) {
     case 1: return launch<1>(st, qkv, output, n_images, tokens, embed_dim, num_heads);
