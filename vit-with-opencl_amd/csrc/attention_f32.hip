@@ -63,17 +63,22 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
 
     /* One LDS-DMA piece = 4 rows x 256 B; lane l fills 16-byte chunk (l & 15) of row
      * 4p + (l >> 4).  which: 1 = K (swizzled), 2 = V (linear). */
-    auto dma = [&](int item, int which, float *dst) {
+    auto dma_piece = [&](const float *base, int which, float *dst, int p) {
+        const int r = 4 * p + (lane >> 4);
+        int c = lane & 15;
+        if (which == 1)
+            c ^= r & 15;
+        const float *src = base + (size_t)min(r, T - 1) * ld + 4 * c; /* rows >= T: finite duplicates */
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + p * 4 * HD), 16, 0, 0);
+    };
+    auto head_base = [&](int item, int which) {
         const int b = item / H, h = item - b * H;
-        const float *base = qkv + (size_t)b * T * ld + (size_t)h * HD + (size_t)which * E;
-        for (int p = wave; p < pieces; p += NKT) {
-            const int r = 4 * p + (lane >> 4);
-            int c = lane & 15;
-            if (which == 1)
-                c ^= r & 15;
-            const float *src = base + (size_t)min(r, T - 1) * ld + 4 * c; /* rows >= T: finite duplicates */
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + p * 4 * HD), 16, 0, 0);
-        }
+        return qkv + (size_t)b * T * ld + (size_t)h * HD + (size_t)which * E;
+    };
+    auto dma = [&](int item, int which, float *dst) {
+        const float *base = head_base(item, which);
+        for (int p = wave; p < pieces; p += NKT)
+            dma_piece(base, which, dst, p);
     };
 
     /* Query fragments: lane's row q = 32*wave + (lane & 31); element e of chunk c is
@@ -130,16 +135,18 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
         const int b = item / H, h = item - b * H;
         const int next = item + gridDim.x;
 
-        /* Both target buffers were released by the barrier that ended the previous item. */
-        dma(item, 2, Vs);
-        if (next < n_items)
-            dma(next, 1, Kn);
-
-        /* Second wave of each SIMD: post its V share first (waiting for the DMA is part
-         * of its hold-back), then sleep out the rest of one MFMA phase. */
+        /* V_n and K_{n+1}: both target buffers were released by the barrier that ended
+         * the previous item.  The second wave of each SIMD issues its share at once (it
+         * is about to be held back anyway); the first waves interleave theirs with the
+         * QK^T tiles so that issuing ~15 DMA instructions does not delay their MFMAs. */
         const bool late = NKT > 4 && wave >= 4;
+        const float *v_src = head_base(item, 2);
+        const float *k_src = head_base(next < n_items ? next : item, 1);
         if (late) {
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            dma(item, 2, Vs);
+            if (next < n_items)
+                dma(next, 1, Kn);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_fetch_add(v_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -165,10 +172,17 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
                 for (int e = 0; e < 4; ++e)
                     s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[j], 0, 0, 0);
             }
+            if (!late) {
+                for (int p = wave + NKT * j; p < pieces; p += NKT * NKT) {
+                    dma_piece(v_src, 2, Vs, p);
+                    if (next < n_items)
+                        dma_piece(k_src, 1, Kn, p);
+                }
+            }
         }
 
         if (!late) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* issued a whole QK^T phase ago */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_fetch_add(v_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
