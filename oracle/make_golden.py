@@ -16,6 +16,8 @@ Fixtures (inputs are regenerated from seeds, never stored):
   b16_stages.npz  per-stage outputs for image 0 / layer 0: small tensors in full,
                   large ones as a stride-37 sample plus fp64 sum and abs-sum
   b16_answer_result.txt  Main.c-format result lines ("[i] label: L / prob: P")
+  b16_full_rounded.npz / b16_answer_result_rounded.txt  the same with weights rounded to 1e-6
+                  as the reference loader delivers them from disk (Network.c:208-211)
 """
 from __future__ import annotations
 
@@ -52,6 +54,7 @@ def main() -> None:
     with tempfile.TemporaryDirectory() as td:
         full = orc.run_reference("full", 0, N_IMAGES, 0, out_path=Path(td) / "full.bin")
         stages = orc.run_reference("stages", 0, out_path=Path(td) / "stages.bin")
+        rounded = orc.run_reference("full_rounded", 0, N_IMAGES, 0, out_path=Path(td) / "rounded.bin")
 
     logits = full["logits"].reshape(N_IMAGES, 1000)
     probs = full["probs"].reshape(N_IMAGES, 1000)
@@ -67,6 +70,15 @@ def main() -> None:
         out[name] = stages[name]
     out["stride"] = np.array(STRIDE)
     np.savez(GOLD / "b16_stages.npz", **out)
+
+    # The file-based flow (Main.c: load_weights rounds every value to 1e-6, Network.c:208-211).
+    rl = rounded["logits"].reshape(N_IMAGES, 1000)
+    rp = rounded["probs"].reshape(N_IMAGES, 1000)
+    np.savez(GOLD / "b16_full_rounded.npz", logits=rl, probs=rp)
+    with open(GOLD / "b16_answer_result_rounded.txt", "w") as f:
+        for i in range(N_IMAGES):
+            k = int(np.argmax(rp[i]))
+            f.write("[%d] label: %d / prob: %.6f\n" % (i, k, rp[i][k]))
 
     # Result lines exactly as Main.c:59-72 prints them, but with a per-image argmax
     # (Main.c:59 never resets pred_idx).

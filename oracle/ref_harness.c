@@ -5,6 +5,8 @@
  * deterministic synthetic inputs of vit_synth_*().  TEST INFRASTRUCTURE ONLY.
  *
  *   ref_harness full   <first_image> <count> <seed_base> <out.bin>
+ *   ref_harness full_rounded <first_image> <count> <seed_base> <out.bin>   (weights rounded to 1e-6
+ *                       like the reference loader does, Network.c:208-211: the file-based flow)
  *   ref_harness stages <seed_base> <out.bin>
  *   ref_harness time   <first_image> <count> <seed_base>       (prints seconds/image)
  *
@@ -18,6 +20,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -84,6 +87,8 @@ static double now_s(void)
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+static int g_round_weights = 0; /* emulate load_weights' rounding (reference Network.c:208-211) */
+
 static Network *make_weights(const vit_config *cfg, unsigned long long seed_base)
 {
     int n = vit_config_num_tensors(cfg);
@@ -92,6 +97,9 @@ static Network *make_weights(const vit_config *cfg, unsigned long long seed_base
         nets[i].size = vit_config_tensor_size(cfg, i);
         nets[i].data = (float *)malloc(sizeof(float) * nets[i].size);
         vit_synth_tensor(cfg, i, seed_base, nets[i].data);
+        if (g_round_weights)
+            for (size_t k = 0; k < nets[i].size; ++k)
+                nets[i].data[k] = roundf(nets[i].data[k] * 1000000.0f) / 1000000.0f;
     }
     return nets;
 }
@@ -196,6 +204,10 @@ int main(int argc, char **argv)
     /* The reference prints six debug lines per layer to stdout (ViT_seq.c:173-181). */
     if (!freopen("/dev/null", "w", stdout))
         return 1;
+    if (argc == 6 && strcmp(argv[1], "full_rounded") == 0) {
+        g_round_weights = 1; /* weights as the reference's loader would deliver them from disk */
+        return run_full(atoi(argv[2]), atoi(argv[3]), strtoull(argv[4], NULL, 10), argv[5], 0);
+    }
     if (argc == 6 && strcmp(argv[1], "full") == 0)
         return run_full(atoi(argv[2]), atoi(argv[3]), strtoull(argv[4], NULL, 10), argv[5], 0);
     if (argc == 5 && strcmp(argv[1], "time") == 0)

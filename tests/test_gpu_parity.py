@@ -263,3 +263,51 @@ def test_vit_l16_one_image_vs_oracle(pkg, device):
     assert np.abs(logits[1] - want_logits).max() <= LOGIT_TOL
     assert int(logits[1].argmax()) == int(want_logits.argmax())
     assert np.abs(probs[1] - want_probs).max() <= 1e-6
+
+
+# torchvision state-dict key of tensor idx (reference file names: Network/Weight_<idx>_<key>.bin)
+def _tensor_name(idx):
+    if idx < 4:
+        return ["class_token", "conv_proj_weight", "conv_proj_bias", "encoder_pos_embedding"][idx]
+    if idx >= 148:
+        return ["encoder_ln_weight", "encoder_ln_bias", "heads_head_weight", "heads_head_bias"][idx - 148]
+    layer, k = divmod(idx - 4, 12)
+    part = ["ln_1_weight", "ln_1_bias", "self_attention_in_proj_weight", "self_attention_in_proj_bias",
+            "self_attention_out_proj_weight", "self_attention_out_proj_bias", "ln_2_weight", "ln_2_bias",
+            "mlp_0_weight", "mlp_0_bias", "mlp_3_weight", "mlp_3_bias"][k]
+    return f"encoder_layers_encoder_layer_{layer}_{part}"
+
+
+def test_c_driver_over_files_matches_reference_flow(pkg, device, weights, tmp_path):
+    """The whole drop-in flow from C, no Python in the process: a synthetic ./Data +
+    ./Network tree in the reference's on-disk formats -> load_image_data / load_weights
+    (with the 1e-6 rounding, Network.c:208-211) -> ViT_opencl -> result file in Main.c's
+    format -> comparator-style check against the answer file produced by the reference's
+    own ViT_seq.c on equally rounded weights (oracle/make_golden.py, full_rounded)."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    L, b = pkg.lib(), pkg.binding
+    root = Path(__file__).resolve().parent.parent
+    exe = root / "vit-with-opencl_amd" / "vit_main"
+    assert exe.exists(), "build with make -C vit-with-opencl_amd/csrc"
+    (tmp_path / "Data").mkdir()
+    (tmp_path / "Network").mkdir()
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 0, 4)
+    assert L.vit_write_image_file(str(tmp_path / "Data" / "input-100.bin").encode(), b.image_array(imgs), 4) == 0
+    for idx, w in enumerate(weights):
+        assert L.vit_write_weight_file(str(tmp_path / "Network").encode(), idx, _tensor_name(idx).encode(),
+                                       b.fptr(w), w.size) == 0
+    shutil.copy(root / "tests" / "golden" / "b16_answer_result_rounded.txt", tmp_path / "Data" / "answer_result.txt")
+    r = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    print(r.stdout[-600:], r.stderr[-600:])
+    assert r.returncode == 0, "comparator reported differences"
+    gold = np.load(root / "tests" / "golden" / "b16_full_rounded.npz")
+    lines = (tmp_path / "Data" / "opencl_result.txt").read_text().splitlines()
+    assert len(lines) == 4
+    for i, line in enumerate(lines):
+        label = int(line.split("label:")[1].split("/")[0])
+        prob = float(line.split("prob:")[1])
+        assert label == int(gold["probs"][i].argmax())
+        assert abs(prob - float(gold["probs"][i].max())) <= 2e-6
