@@ -58,6 +58,7 @@ int vh_device_sync(void);
 int vh_event_create(vh_event_t *out);
 int vh_event_destroy(vh_event_t e);
 int vh_event_record(vh_event_t e, vh_stream_t s);
+int vh_stream_wait_event(vh_stream_t s, vh_event_t e); /* work queued on s after this waits for e */
 int vh_event_sync(vh_event_t e);
 int vh_event_elapsed_ms(float *ms, vh_event_t start, vh_event_t stop);
 

@@ -55,12 +55,14 @@ struct vit_hip_ctx
     float *cls;         /* normalised CLS rows  [max_batch][E] */
     float *d_logits;    /* [max_batch][classes] */
     float *d_probs;     /* [max_batch][classes] */
-    float *d_images;    /* [max_batch][C][H][W] staging target for the host API */
-
-    /* pinned host staging for the host-pointer API */
-    float *h_images;
-    float *h_logits;
-    float *h_probs;
+    /* host-pointer API: two staging slots so that gathering + uploading chunk k+1
+     * overlaps the compute of chunk k (pinned host memory, second stream, events) */
+    float *d_images[2]; /* [max_batch][C][H][W] */
+    float *h_images[2];
+    float *h_logits[2];
+    float *h_probs[2];
+    vh_stream_t copy_stream;
+    vh_event_t up_done[2], comp_done[2], out_done[2];
 
     /* optional per-operator timing with HIP events on the launch stream */
     vh_event_t *prof_ev;   /* 2 events per recorded launch */
@@ -132,14 +134,22 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
         vh_stream_sync(ctx->stream);
     prof_release(ctx);
     float *dev[] = {ctx->w_slab, ctx->x, ctx->y, ctx->attn, ctx->qkv, ctx->hid,
-                    ctx->cls, ctx->d_logits, ctx->d_probs, ctx->d_images};
+                    ctx->cls, ctx->d_logits, ctx->d_probs, ctx->d_images[0], ctx->d_images[1]};
     for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); ++i)
         if (dev[i])
             vh_free(dev[i]);
-    float *host[] = {ctx->h_images, ctx->h_logits, ctx->h_probs};
+    float *host[] = {ctx->h_images[0], ctx->h_images[1], ctx->h_logits[0], ctx->h_logits[1],
+                     ctx->h_probs[0], ctx->h_probs[1]};
     for (size_t i = 0; i < sizeof(host) / sizeof(host[0]); ++i)
         if (host[i])
             vh_host_free(host[i]);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->up_done[i]) vh_event_destroy(ctx->up_done[i]);
+        if (ctx->comp_done[i]) vh_event_destroy(ctx->comp_done[i]);
+        if (ctx->out_done[i]) vh_event_destroy(ctx->out_done[i]);
+    }
+    if (ctx->copy_stream)
+        vh_stream_destroy(ctx->copy_stream);
     if (ctx->stream)
         vh_stream_destroy(ctx->stream);
     free(ctx->w);
@@ -206,10 +216,16 @@ int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *netw
     TRY(vh_malloc((void **)&ctx->cls, (size_t)max_batch * E * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->d_logits, (size_t)max_batch * NC * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->d_probs, (size_t)max_batch * NC * sizeof(float)));
-    TRY(vh_malloc((void **)&ctx->d_images, (size_t)max_batch * img * sizeof(float)));
-    TRY(vh_host_alloc((void **)&ctx->h_images, (size_t)max_batch * img * sizeof(float)));
-    TRY(vh_host_alloc((void **)&ctx->h_logits, (size_t)max_batch * NC * sizeof(float)));
-    TRY(vh_host_alloc((void **)&ctx->h_probs, (size_t)max_batch * NC * sizeof(float)));
+    TRY(vh_stream_create(&ctx->copy_stream));
+    for (int i = 0; i < 2; ++i) {
+        TRY(vh_malloc((void **)&ctx->d_images[i], (size_t)max_batch * img * sizeof(float)));
+        TRY(vh_host_alloc((void **)&ctx->h_images[i], (size_t)max_batch * img * sizeof(float)));
+        TRY(vh_host_alloc((void **)&ctx->h_logits[i], (size_t)max_batch * NC * sizeof(float)));
+        TRY(vh_host_alloc((void **)&ctx->h_probs[i], (size_t)max_batch * NC * sizeof(float)));
+        TRY(vh_event_create(&ctx->up_done[i]));
+        TRY(vh_event_create(&ctx->comp_done[i]));
+        TRY(vh_event_create(&ctx->out_done[i]));
+    }
     TRY(vh_stream_sync(ctx->stream));
     *out = ctx;
     return 0;
@@ -312,6 +328,22 @@ fail:
     return rc;
 }
 
+/* Host-pointer forward, software-pipelined over chunks of max_batch images:
+ *   host     : gather chunk k into pinned slot k&1   | scatter outputs of chunk k-1
+ *   copy strm: H2D chunk k                            (after compute of chunk k-2 released the slot)
+ *   compute  : forward chunk k, D2H its logits/probs  (after the H2D)
+ * so PCIe and the gather of the separately malloc'd images (Network.c:90) hide under
+ * the previous chunk's kernels. */
+static void scatter_outputs(vit_hip_ctx *ctx, int slot, int first, int m, float *logits, float **probs)
+{
+    const size_t NC = (size_t)ctx->cfg.num_classes;
+    if (logits)
+        memcpy(logits + (size_t)first * NC, ctx->h_logits[slot], (size_t)m * NC * sizeof(float));
+    if (probs)
+        for (int i = 0; i < m; ++i)
+            memcpy(probs[first + i], ctx->h_probs[slot] + (size_t)i * NC, NC * sizeof(float));
+}
+
 int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *logits, float **probs)
 {
     int rc = 0;
@@ -320,32 +352,46 @@ int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *log
     const vit_config *c = &ctx->cfg;
     const size_t img = (size_t)c->in_chans * c->img_size * c->img_size;
     const size_t NC = (size_t)c->num_classes;
+    for (int i = 0; i < n; ++i)
+        if (!images[i].data || images[i].c != c->in_chans || images[i].h != c->img_size ||
+            images[i].w != c->img_size)
+            return 5;
 
-    for (int first = 0; first < n; first += ctx->max_batch) {
+    int prev_first = 0, prev_m = 0, k = 0;
+    for (int first = 0; first < n; first += ctx->max_batch, ++k) {
         const int m = (n - first < ctx->max_batch) ? n - first : ctx->max_batch;
-        /* gather the separately malloc'd images (Network.c:90) into pinned staging */
-        for (int i = 0; i < m; ++i) {
-            const ImageData *im = &images[first + i];
-            if (!im->data || im->c != c->in_chans || im->h != c->img_size || im->w != c->img_size)
-                return 5;
-            memcpy(ctx->h_images + (size_t)i * img, im->data, img * sizeof(float));
-        }
-        TRY(vh_h2d(ctx->d_images, ctx->h_images, (size_t)m * img * sizeof(float), ctx->stream));
-        TRY(vit_hip_forward_device(ctx, ctx->d_images, m, ctx->d_logits, probs ? ctx->d_probs : NULL,
+        const int s = k & 1;
+        /* slot s was last used by chunk k-2, whose outputs were waited for below */
+        for (int i = 0; i < m; ++i)
+            memcpy(ctx->h_images[s] + (size_t)i * img, images[first + i].data, img * sizeof(float));
+        if (k >= 2)
+            TRY(vh_stream_wait_event(ctx->copy_stream, ctx->comp_done[s]));
+        TRY(vh_h2d(ctx->d_images[s], ctx->h_images[s], (size_t)m * img * sizeof(float), ctx->copy_stream));
+        TRY(vh_event_record(ctx->up_done[s], ctx->copy_stream));
+
+        TRY(vh_stream_wait_event(ctx->stream, ctx->up_done[s]));
+        TRY(vit_hip_forward_device(ctx, ctx->d_images[s], m, ctx->d_logits, probs ? ctx->d_probs : NULL,
                                    ctx->stream));
+        TRY(vh_event_record(ctx->comp_done[s], ctx->stream));
         if (logits)
-            TRY(vh_d2h(ctx->h_logits, ctx->d_logits, (size_t)m * NC * sizeof(float), ctx->stream));
+            TRY(vh_d2h(ctx->h_logits[s], ctx->d_logits, (size_t)m * NC * sizeof(float), ctx->stream));
         if (probs)
-            TRY(vh_d2h(ctx->h_probs, ctx->d_probs, (size_t)m * NC * sizeof(float), ctx->stream));
-        TRY(vh_stream_sync(ctx->stream));
-        if (logits)
-            memcpy(logits + (size_t)first * NC, ctx->h_logits, (size_t)m * NC * sizeof(float));
-        if (probs)
-            for (int i = 0; i < m; ++i)
-                memcpy(probs[first + i], ctx->h_probs + (size_t)i * NC, NC * sizeof(float));
+            TRY(vh_d2h(ctx->h_probs[s], ctx->d_probs, (size_t)m * NC * sizeof(float), ctx->stream));
+        TRY(vh_event_record(ctx->out_done[s], ctx->stream));
+
+        if (k >= 1) { /* finish chunk k-1 while chunk k runs */
+            TRY(vh_event_sync(ctx->out_done[s ^ 1]));
+            scatter_outputs(ctx, s ^ 1, prev_first, prev_m, logits, probs);
+        }
+        prev_first = first;
+        prev_m = m;
     }
+    TRY(vh_event_sync(ctx->out_done[(k - 1) & 1]));
+    scatter_outputs(ctx, (k - 1) & 1, prev_first, prev_m, logits, probs);
     return 0;
 fail:
+    vh_stream_sync(ctx->copy_stream);
+    vh_stream_sync(ctx->stream);
     return rc;
 }
 

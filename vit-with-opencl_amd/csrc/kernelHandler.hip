@@ -94,6 +94,11 @@ int vh_event_create(vh_event_t *out)
 }
 int vh_event_destroy(vh_event_t e) { VH_TRY(hipEventDestroy((hipEvent_t)e)); return 0; }
 int vh_event_record(vh_event_t e, vh_stream_t s) { VH_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); return 0; }
+int vh_stream_wait_event(vh_stream_t s, vh_event_t e)
+{
+    VH_TRY(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0));
+    return 0;
+}
 int vh_event_sync(vh_event_t e) { VH_TRY(hipEventSynchronize((hipEvent_t)e)); return 0; }
 int vh_event_elapsed_ms(float *ms, vh_event_t start, vh_event_t stop)
 {

@@ -25,7 +25,8 @@ voidp = C.c_void_p
 EXPORTS = [
     "vh_device_count", "vh_init", "vh_last_error", "vh_device_name",
     "vh_stream_create", "vh_stream_destroy", "vh_stream_sync", "vh_device_sync",
-    "vh_event_create", "vh_event_destroy", "vh_event_record", "vh_event_sync", "vh_event_elapsed_ms",
+    "vh_event_create", "vh_event_destroy", "vh_event_record", "vh_stream_wait_event", "vh_event_sync",
+    "vh_event_elapsed_ms",
     "vh_malloc", "vh_free", "vh_host_alloc", "vh_host_free", "vh_memset", "vh_h2d", "vh_d2h", "vh_d2d",
     "vh_launch_patch_embed", "vh_launch_layer_norm", "vh_launch_linear", "vh_launch_attention",
     "vh_launch_softmax",
@@ -106,6 +107,7 @@ def lib() -> C.CDLL:
     L.vh_event_create.argtypes = [C.POINTER(voidp)]
     L.vh_event_destroy.argtypes = [voidp]
     L.vh_event_record.argtypes = [voidp, voidp]
+    L.vh_stream_wait_event.argtypes = [voidp, voidp]
     L.vh_event_sync.argtypes = [voidp]
     L.vh_event_elapsed_ms.argtypes = [C.POINTER(C.c_float), voidp, voidp]
     L.vh_malloc.argtypes = [C.POINTER(voidp), sz]
