@@ -203,10 +203,20 @@ def main() -> None:
         fc1_ms, fc1_cnt = prof["fc1_gemm"]
         fc1_flops_per_launch = 2.0 * B * tokens * cfg.embed_dim * cfg.mlp_hidden
         achieved = fc1_flops_per_launch / (fc1_ms / fc1_cnt * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel<A_ROWS,EPI_GELU> (fc1: M=%d N=%d K=%d)" %
+        # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes
+        # (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); bench.py cannot collect PMCs itself.
+        traffic, traffic_src = None, None
+        pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
+        if pmc.exists() and B == 512:
+            traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, B=512)"
+        roofline = {"bound": "mfma",
+                    "kernel": "gemm_f32_kernel<Tile<256,256,4,4>,A_ROWS,EPI_GELU,false> (fc1: M=%d N=%d K=%d)" %
                     (B * tokens, cfg.mlp_hidden, cfg.embed_dim),
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes": (B * tokens * (cfg.embed_dim + cfg.mlp_hidden) + cfg.mlp_hidden * cfg.embed_dim) * 4}
 
         # sanity of what was computed + parity against the CPU path in the same run
         if comm is not None:
