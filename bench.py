@@ -93,6 +93,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the parity path (default, what `value` is quoted on); bf16 = bf16-operand GEMMs "
+                         "(BASELINE config 3; logits ~1e-2 from ViT_seq.c, so never the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -121,7 +124,7 @@ def main() -> None:
     B, NC = args.batch, cfg.num_classes
 
     weights = pkg.synth_weights(cfg, 0)
-    model = pkg.ViTHip(cfg, weights, device=device, max_batch=B)
+    model = pkg.ViTHip(cfg, weights, device=device, max_batch=B, precision=args.dtype)
     L = pkg.lib()
 
     # Synthetic batch, distinct images per rank: global image index = rank*B + i.  Generated
@@ -177,6 +180,34 @@ def main() -> None:
     if comm is not None:
         elapsed = comm.max_over_ranks(elapsed)
 
+    # Secondary leg (N=1, default dtype only): the same step with bf16-operand GEMMs, reported
+    # beside -- never instead of -- the fp32 `value`.
+    bf16_leg = None
+    if comm is None and args.dtype == "f32":
+        m16 = pkg.ViTHip(cfg, weights, device=device, max_batch=B, precision="bf16")
+        d_l16 = pkg.DeviceBuffer(B * NC)
+        for _ in range(2):
+            m16.forward_device(d_images.ptr, B, d_l16.ptr, d_probs.ptr, m16.stream)
+        pkg.binding.check(L.vh_device_sync(), "sync")
+        m16.profile_enable(5)
+        t16 = time.perf_counter()
+        for _ in range(5):
+            m16.forward_device(d_images.ptr, B, d_l16.ptr, d_probs.ptr, m16.stream)
+        pkg.binding.check(L.vh_device_sync(), "sync")
+        dt16 = (time.perf_counter() - t16) / 5
+        p16 = m16.profile_read()
+        l16 = d_l16.to_numpy((B, NC))
+        l32 = d_logits.to_numpy((B, NC))
+        bf16_leg = {"dtype": "bf16 GEMM operands, fp32 accumulate/residual/attention", "value": round(B / dt16, 1),
+                    "unit": "images/sec", "ms_per_step": round(dt16 * 1e3, 3),
+                    "max_abs_dlogit_vs_f32_path": float(np.abs(l16 - l32).max()),
+                    "argmax_agreement_with_f32_path": float((l16.argmax(1) == l32.argmax(1)).mean()),
+                    "kernels_avg_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in p16.items() if cnt}}
+        m16.close()
+        # restore the fp32 path's probabilities for the checks below
+        model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
+        pkg.binding.check(L.vh_device_sync(), "sync")
+
     if rank == 0:
         flops = model_flops(cfg, tokens)
         total_flops = sum(flops.values())
@@ -203,18 +234,19 @@ def main() -> None:
         fc1_ms, fc1_cnt = prof["fc1_gemm"]
         fc1_flops_per_launch = 2.0 * B * tokens * cfg.embed_dim * cfg.mlp_hidden
         achieved = fc1_flops_per_launch / (fc1_ms / fc1_cnt * 1e-3) / 1e12
+        peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0   # dense bf16 MFMA, same guide
         # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes
         # (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); bench.py cannot collect PMCs itself.
         traffic, traffic_src = None, None
         pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if pmc.exists() and B == 512:
+        if pmc.exists() and B == 512 and args.dtype == "f32":
             traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
             traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, B=512)"
         roofline = {"bound": "mfma",
                     "kernel": "gemm_f32_kernel<Tile<256,256,4,4>,A_ROWS,EPI_GELU,false> (fc1: M=%d N=%d K=%d)" %
                     (B * tokens, cfg.mlp_hidden, cfg.embed_dim),
-                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak_tf, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "algorithmic_bytes": (B * tokens * (cfg.embed_dim + cfg.mlp_hidden) + cfg.mlp_hidden * cfg.embed_dim) * 4}
 
@@ -228,7 +260,7 @@ def main() -> None:
         out = {
             "metric": "images/sec ViT-B/16 224x224 bs512", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"ViT-B/16 224x224 fp32 forward (patch-embed..softmax), batch {B} per GPU, "
                                    f"device-resident inputs, random-init weights", "global_batch": world * B,
@@ -237,6 +269,8 @@ def main() -> None:
             "model_frac_of_f32_mfma_peak": round(total_flops * B * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roofline, "kernels": kernels,
         }
+        if bf16_leg is not None:
+            out["bf16_gemm_mode"] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:
             nproc = args.cpu_procs or max(1, min(os.cpu_count() or 1, 16))
             base, ref_logits = cpu_baseline(nproc)

@@ -71,6 +71,18 @@ int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *netw
                    int n_tensors, int device, int max_batch);
 void vit_hip_destroy(vit_hip_ctx *ctx);
 
+/* Arithmetic of the dense projections.  F32 is the parity path (class logits within
+ * 1e-4 of ViT_seq.c).  BF16_GEMM (BASELINE config 3) rounds the GEMM operands --
+ * LayerNorm outputs, attention output, MLP hidden layer, and the QKV / out-proj / fc1 /
+ * fc2 weights -- to bfloat16 and accumulates in fp32; the residual stream, attention
+ * arithmetic, norms and classifier stay fp32.  Its logits differ from ViT_seq.c by
+ * ~1e-2 (tests/test_gpu_parity.py states the tolerance), so it is opt-in:
+ * vit_hip_create() uses F32 unless $VIT_HIP_PRECISION=bf16. */
+enum { VIT_PRECISION_F32 = 0, VIT_PRECISION_BF16_GEMM = 1 };
+int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
+                      int n_tensors, int device, int max_batch, int precision);
+int vit_hip_precision(const vit_hip_ctx *ctx);
+
 /* Host-pointer forward: gathers the n separately allocated images into pinned
  * staging, runs them in chunks of <= max_batch, and returns when all outputs
  * are in host memory.  `logits` ([n][num_classes], contiguous) and `probs`

@@ -123,6 +123,23 @@ int vh_launch_attention(vh_stream_t s, const float *qkv, float *output, int n_im
  * ViT_seq.c:372. */
 int vh_launch_softmax(vh_stream_t s, const float *input, float *output, int rows, int length);
 
+/* ---- bf16-operand variants (BASELINE config 3: "bf16 ... MFMA QKV/MLP GEMMs") ----
+ * No reference counterpart (the reference is fp32 throughout).  GEMM operands are bf16
+ * with fp32 accumulation; the residual stream, biases, LayerNorm statistics, the
+ * attention arithmetic and the classifier stay fp32.  A producer whose only consumer
+ * is a bf16 GEMM rounds to bf16 when it stores (identical to rounding at the GEMM's
+ * input, half the bytes): LayerNorm output, attention output, the MLP hidden layer. */
+int vh_launch_convert_bf16(vh_stream_t s, const float *input, void *output, size_t count);
+int vh_launch_layer_norm_bf16(vh_stream_t s, const float *input, const float *weight,
+                              const float *bias, void *output, int rows, int embed_dim,
+                              long in_row_stride, long out_row_stride, double eps);
+/* output (fp32, or bf16 when output_bf16) = input_bf16 . weight_bf16^T + bias [+GELU | +residual] */
+int vh_launch_linear_bf16(vh_stream_t s, void *output, int output_bf16, const void *weight,
+                          const void *input, const float *bias, int rowA, int colA, int colB,
+                          int doGelu, const float *residual);
+int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *output, int n_images,
+                             int tokens, int embed_dim, int num_heads);
+
 #ifdef __cplusplus
 }
 #endif

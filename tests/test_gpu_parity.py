@@ -311,3 +311,83 @@ def test_c_driver_over_files_matches_reference_flow(pkg, device, weights, tmp_pa
         prob = float(line.split("prob:")[1])
         assert label == int(gold["probs"][i].argmax())
         assert abs(prob - float(gold["probs"][i].max())) <= 2e-6
+
+
+# ---- bf16-operand GEMM mode (BASELINE config 3) -------------------------------------
+
+
+def _to_bf16_bits(a):
+    """fp32 -> bf16 bit patterns, round to nearest even (what v_cvt_pk_bf16_f32 does)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def _bf16_bits_to_f32(r):
+    return (r.astype(np.uint32) << 16).view(np.float32)
+
+
+def _dev_raw(pkg, arr):
+    """Upload any contiguous array as raw bytes."""
+    arr = np.ascontiguousarray(arr)
+    d = pkg.DeviceBuffer((arr.nbytes + 3) // 4)
+    L = pkg.lib()
+    assert L.vh_h2d(d.ptr, arr.ctypes.data, arr.nbytes, None) == 0 and L.vh_device_sync() == 0
+    return d
+
+
+def test_convert_bf16_rounds_to_nearest_even(pkg, device, oracle):
+    x = oracle.synth_fill(100003, 3, 2.0, 0.0)
+    d_x, d_y = _dev(pkg, x), pkg.DeviceBuffer((x.size + 1) // 2)
+    _launch(pkg, "vh_launch_convert_bf16", None, d_x.ptr, d_y.ptr, x.size)
+    got = d_y.to_numpy().view(np.uint16)[:x.size]
+    assert np.array_equal(got, _to_bf16_bits(x))
+
+
+@pytest.mark.parametrize("M,K,N,gelu,resid,out16", [
+    (197, 768, 2304, 0, False, False),   # QKV: bf16 in, fp32 out
+    (197, 768, 768, 0, True, False),     # out-proj + residual
+    (197, 768, 3072, 1, False, True),    # fc1 + GELU, bf16 out
+    (300, 3072, 768, 0, True, False),    # fc2 + residual, ragged M
+    (5, 64, 128, 0, False, True),        # smallest legal shape
+])
+def test_linear_bf16_vs_oracle_on_rounded_operands(pkg, device, oracle, M, K, N, gelu, resid, out16):
+    """bf16 operands, fp32 accumulate: the oracle's fp32 loop on the SAME bf16-rounded
+    operands differs only by summation order -> the fp32 operator tolerance applies."""
+    x16 = _to_bf16_bits(oracle.synth_fill(M * K, 500 + M, 1.0, 0.1).reshape(M, K))
+    w16 = _to_bf16_bits(oracle.synth_fill(N * K, 600 + N, 0.04, 0.0))
+    b = oracle.synth_fill(N, 700 + N, 0.1, 0.0)
+    r = oracle.synth_fill(M * N, 800, 1.0, 0.0).reshape(M, N)
+    want = oracle.linear(_bf16_bits_to_f32(x16), _bf16_bits_to_f32(w16), b, N)
+    if gelu:
+        want = oracle.gelu(want.ravel()).reshape(M, N)
+    if resid:
+        want = r + want
+    d_x, d_w, d_b = _dev_raw(pkg, x16), _dev_raw(pkg, w16), _dev(pkg, b)
+    d_out = _dev(pkg, r) if resid else pkg.DeviceBuffer(M * N)
+    _launch(pkg, "vh_launch_linear_bf16", None, d_out.ptr, int(out16), d_w.ptr, d_x.ptr, d_b.ptr, M, K, N, gelu,
+            d_out.ptr if resid else None)
+    if out16:
+        got = _bf16_bits_to_f32(d_out.to_numpy().view(np.uint16)[:M * N]).reshape(M, N)
+        assert np.abs(got - want).max() <= 2.0 ** -8 * np.abs(want).max() + OP_TOL   # one bf16 rounding
+    else:
+        got = d_out.to_numpy((M, N))
+        assert np.abs(got - want).max() <= OP_TOL
+
+
+def test_model_bf16_gemm_mode(pkg, device, weights, golden_full):
+    """BASELINE config 3 (bf16 MFMA QKV/MLP GEMMs): stated tolerance for the class logits is
+    4e-2 absolute against ViT_seq.c (operands carry 8 significant bits; measured ~1e-2),
+    probabilities within 2e-4, arg-max equal wherever the reference's top-2 margin
+    exceeds twice that tolerance."""
+    cfg = pkg.preset("vit_b_16")
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=4, precision="bf16")
+    logits, probs = m.forward(pkg.synth_images(cfg, 0, 4))
+    m.close()
+    ref = golden_full["logits"]
+    dl = np.abs(logits - ref).max(axis=1)
+    print("bf16-GEMM mode: max |dlogit| per image:", dl)
+    assert np.isfinite(logits).all() and dl.max() <= 4e-2
+    assert np.abs(probs - golden_full["probs"]).max() <= 2e-4
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 8e-2
+    assert np.array_equal(logits.argmax(1)[clear], ref.argmax(1)[clear]) and clear.any()

@@ -45,6 +45,9 @@ struct vit_hip_ctx
 
     float *w_slab;      /* all weights, one allocation */
     float **w;          /* device pointer per tensor index */
+    int precision;      /* VIT_PRECISION_F32 or VIT_PRECISION_BF16_GEMM */
+    void *w16_slab;     /* bf16 copies of the four big matrices of every layer */
+    void **w16;         /* per tensor index (NULL where no bf16 copy exists) */
 
     /* activation arena (rows = max_batch * tokens) */
     float *x;           /* residual stream      [rows][E]   */
@@ -133,6 +136,9 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
     if (ctx->stream)
         vh_stream_sync(ctx->stream);
     prof_release(ctx);
+    if (ctx->w16_slab)
+        vh_free(ctx->w16_slab);
+    free(ctx->w16);
     float *dev[] = {ctx->w_slab, ctx->x, ctx->y, ctx->attn, ctx->qkv, ctx->hid,
                     ctx->cls, ctx->d_logits, ctx->d_probs, ctx->d_images[0], ctx->d_images[1]};
     for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); ++i)
@@ -159,8 +165,20 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
 int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                    int n_tensors, int device, int max_batch)
 {
+    const char *env = getenv("VIT_HIP_PRECISION");
+    const int precision = (env && env[0] == 'b') ? VIT_PRECISION_BF16_GEMM : VIT_PRECISION_F32;
+    return vit_hip_create_ex(out, cfg, networks, n_tensors, device, max_batch, precision);
+}
+
+int vit_hip_precision(const vit_hip_ctx *ctx) { return ctx->precision; }
+
+int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
+                      int n_tensors, int device, int max_batch, int precision)
+{
     int rc = 0;
     if (!out || !cfg || !networks || max_batch <= 0)
+        return 1;
+    if (precision != VIT_PRECISION_F32 && precision != VIT_PRECISION_BF16_GEMM)
         return 1;
     *out = NULL;
     if (n_tensors != vit_config_num_tensors(cfg))
@@ -184,8 +202,12 @@ int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *netw
     ctx->max_batch = max_batch;
     ctx->tokens = vit_config_tokens(cfg);
     ctx->n_tensors = n_tensors;
+    ctx->precision = precision;
     ctx->w = (float **)calloc((size_t)n_tensors, sizeof(float *));
-    if (!ctx->w) {
+    ctx->w16 = (void **)calloc((size_t)n_tensors, sizeof(void *));
+    if (!ctx->w || !ctx->w16) {
+        free(ctx->w);
+        free(ctx->w16);
         free(ctx);
         return 4;
     }
@@ -203,6 +225,25 @@ int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *netw
         ctx->w[i] = (float *)((char *)ctx->w_slab + off);
         TRY(vh_h2d(ctx->w[i], networks[i].data, networks[i].size * sizeof(float), ctx->stream));
         off += align_up(networks[i].size * sizeof(float), 256);
+    }
+
+    if (precision == VIT_PRECISION_BF16_GEMM) {
+        /* bf16 copies of in_proj, out_proj, fc1, fc2 of every layer (the GEMM operands);
+         * everything else (norms, biases, embeddings, classifier) stays fp32 */
+        static const int big[4] = {2, 4, 8, 10};
+        size_t total16 = 0;
+        for (int l = 0; l < cfg->depth; ++l)
+            for (int k = 0; k < 4; ++k)
+                total16 += align_up(networks[4 + 12 * l + big[k]].size * 2, 256);
+        TRY(vh_malloc(&ctx->w16_slab, total16));
+        size_t off16 = 0;
+        for (int l = 0; l < cfg->depth; ++l)
+            for (int k = 0; k < 4; ++k) {
+                const int idx = 4 + 12 * l + big[k];
+                ctx->w16[idx] = (char *)ctx->w16_slab + off16;
+                TRY(vh_launch_convert_bf16(ctx->stream, ctx->w[idx], ctx->w16[idx], networks[idx].size));
+                off16 += align_up(networks[idx].size * 2, 256);
+            }
     }
 
     const size_t E = (size_t)cfg->embed_dim, F = (size_t)cfg->mlp_hidden, NC = (size_t)cfg->num_classes;
@@ -250,7 +291,20 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n,
                                                  c->in_chans, c->img_size, c->patch_size, E));
 
-    for (int l = 0; l < c->depth; ++l) {
+    for (int l = 0; l < c->depth && ctx->precision == VIT_PRECISION_BF16_GEMM; ++l) {
+        /* bf16 GEMM operands: y, attn and hid hold bf16 (same allocations, half used);
+         * the residual stream x, the fused qkv and all statistics stay fp32 */
+        float **lw = w + 4 + 12 * l;
+        void **lw16 = ctx->w16 + 4 + 12 * l;
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_bf16(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
+        OP(VIT_OP_QKV, vh_launch_linear_bf16(s, ctx->qkv, 0, lw16[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+        OP(VIT_OP_ATTENTION, vh_launch_attention_bf16(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+        OP(VIT_OP_OUT_PROJ, vh_launch_linear_bf16(s, ctx->x, 0, lw16[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_bf16(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
+        OP(VIT_OP_FC1, vh_launch_linear_bf16(s, ctx->hid, 1, lw16[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+        OP(VIT_OP_FC2, vh_launch_linear_bf16(s, ctx->x, 0, lw16[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+    }
+    for (int l = 0; l < c->depth && ctx->precision == VIT_PRECISION_F32; ++l) {
         float **lw = w + 4 + 12 * l; /* ln1 w,b; in w,b; out w,b; ln2 w,b; fc1 w,b; fc2 w,b */
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
         OP(VIT_OP_QKV, vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));

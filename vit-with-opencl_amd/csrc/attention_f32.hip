@@ -46,9 +46,9 @@ constexpr int MAX_ROWS = (MAX_LDS - 64) / (3 * HD * 4) / 8 * 8; /* rows per buff
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int NKT> /* number of 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT */
+template <int NKT, bool OUTBF16> /* NKT 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT */
 __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__restrict__ qkv,
-                                                                float *__restrict__ out, int T,
+                                                                void *__restrict__ out, int T,
                                                                 int E, int H, int n_items, int RB)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -265,13 +265,19 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
         }
 
         if (q < T) {
-            float *dst = out + ((size_t)b * T + q) * E + (size_t)h * HD + 4 * lh;
+            const size_t off = ((size_t)b * T + q) * E + (size_t)h * HD + 4 * lh;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-                    *reinterpret_cast<f32x4 *>(dst + dt * 32 + 8 * g) = v;
+                    if (OUTBF16) { /* consumed only by the bf16-operand output projection */
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 v16 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(out) + off + dt * 32 + 8 * g) = v16;
+                    } else {
+                        *reinterpret_cast<f32x4 *>(static_cast<float *>(out) + off + dt * 32 + 8 * g) = v;
+                    }
                 }
         }
 
@@ -281,14 +287,14 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
     }
 }
 
-template <int NKT>
-int launch(hipStream_t st, const float *qkv, float *out, int n_images, int T, int E, int H)
+template <int NKT, bool OUTBF16>
+int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, int E, int H)
 {
     const int RB = (T + 7) / 8 * 8; /* rows per buffer: whole 8-key register groups, whole 4-row DMA pieces */
     const size_t lds = sizeof(float) * 3 * RB * HD + 64;
     static bool attr_set = false;
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)attention_f32_kernel<NKT>,
+        VH_TRY(hipFuncSetAttribute((const void *)attention_f32_kernel<NKT, OUTBF16>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         attr_set = true;
     }
@@ -302,16 +308,23 @@ int launch(hipStream_t st, const float *qkv, float *out, int n_images, int T, in
     }
     const int n_items = n_images * H;
     const int grid = n_items < num_cus ? n_items : num_cus;
-    hipLaunchKernelGGL((attention_f32_kernel<NKT>), dim3(grid), dim3(64 * NKT), lds, st, qkv, out, T, E,
-                       H, n_items, RB);
+    hipLaunchKernelGGL((attention_f32_kernel<NKT, OUTBF16>), dim3(grid), dim3(64 * NKT), lds, st, qkv, out,
+                       T, E, H, n_items, RB);
     VH_LAUNCH_CHECK("attention_f32_kernel");
     return 0;
 }
 
+template <int NKT>
+int launch(hipStream_t st, const float *qkv, void *out, int out_bf16, int n_images, int T, int E, int H)
+{
+    return out_bf16 ? launch_k<NKT, true>(st, qkv, out, n_images, T, E, H)
+                    : launch_k<NKT, false>(st, qkv, out, n_images, T, E, H);
+}
+
 } // namespace
 
-extern "C" int vh_launch_attention(vh_stream_t s, const float *qkv, float *output, int n_images,
-                                   int tokens, int embed_dim, int num_heads)
+static int launch_attention(vh_stream_t s, const float *qkv, void *output, int out_bf16, int n_images,
+                            int tokens, int embed_dim, int num_heads)
 {
     if (!qkv || !output)
         return vh_fail(1, "vh_launch_attention: null pointer argument");
@@ -323,12 +336,24 @@ extern "C" int vh_launch_attention(vh_stream_t s, const float *qkv, float *outpu
                        tokens, MAX_ROWS);
     hipStream_t st = (hipStream_t)s;
     switch ((tokens + 31) / 32) {
-    case 1: return launch<1>(st, qkv, output, n_images, tokens, embed_dim, num_heads);
-    case 2: return launch<2>(st, qkv, output, n_images, tokens, embed_dim, num_heads);
-    case 3: return launch<3>(st, qkv, output, n_images, tokens, embed_dim, num_heads);
-    case 4: return launch<4>(st, qkv, output, n_images, tokens, embed_dim, num_heads);
-    case 5: return launch<5>(st, qkv, output, n_images, tokens, embed_dim, num_heads);
-    case 6: return launch<6>(st, qkv, output, n_images, tokens, embed_dim, num_heads);
-    default: return launch<7>(st, qkv, output, n_images, tokens, embed_dim, num_heads);
+    case 1: return launch<1>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    case 2: return launch<2>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    case 3: return launch<3>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    case 4: return launch<4>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    case 5: return launch<5>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    case 6: return launch<6>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    default: return launch<7>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
     }
+}
+
+extern "C" int vh_launch_attention(vh_stream_t s, const float *qkv, float *output, int n_images,
+                                   int tokens, int embed_dim, int num_heads)
+{
+    return launch_attention(s, qkv, output, 0, n_images, tokens, embed_dim, num_heads);
+}
+
+extern "C" int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *output, int n_images,
+                                        int tokens, int embed_dim, int num_heads)
+{
+    return launch_attention(s, qkv, output, 1, n_images, tokens, embed_dim, num_heads);
 }

@@ -1,6 +1,6 @@
 /*
- * gemm_f32.hip -- the dense projections of the ViT forward pass on the gfx950
- * matrix cores, in exact fp32.
+ * gemm_mfma.hip -- the dense projections of the ViT forward pass on the gfx950
+ * matrix cores: exact fp32 (the parity path) and bf16 operands with fp32 accumulation.
  *
  *   C[M][N] = A[M][K] . W[N][K]^T  (+ bias, + GELU | + residual | patch epilogue)
  *
@@ -45,7 +45,9 @@
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK = 32;   /* 32-bit words per LDS row: 32 fp32 or 64 bf16 K elements per K step */
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { A_ROWS = 0, A_PATCH = 1 };
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
@@ -72,8 +74,9 @@ struct Tile {
 };
 
 struct GemmParams {
-    const float *A, *W, *bias, *R, *pos;
-    float *C;
+    const void *A, *W;        /* operands: fp32 or bf16, row-major [M][K] and [N][K] */
+    const float *bias, *R, *pos;
+    void *C;                  /* output: fp32 or bf16 */
     int M, N, K;
     int mtiles, ntiles;
     /* patch-embed geometry (A_PATCH / EPI_PATCH only) */
@@ -118,10 +121,16 @@ __device__ __forceinline__ float gelu_exact(float x)
     return 0.5f * x * (1.0f + erf_a);
 }
 
-template <class T, int AMODE, int EPI, bool NGUARD>
+/* BF16IN: A and W are bf16 (one ds_read_b128 = 8 K elements = one v_mfma_f32_32x32x16_bf16
+ * operand, natural k order); otherwise fp32 (four v_mfma_f32_32x32x2_f32 per read).
+ * BF16OUT: the result is rounded to bf16 (it feeds the next bf16 GEMM and nothing else). */
+template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false>
 __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(const GemmParams p)
 {
     constexpr int BM = T::BM, BN = T::BN, IT = T::IT, JT = T::JT;
+    constexpr int ES = BF16IN ? 2 : 4;   /* operand element size */
+    constexpr int KE = 128 / ES;         /* K elements per step (one 128-byte LDS row) */
+    static_assert(!(BF16IN && AMODE == A_PATCH), "im2row loader is fp32 only");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -135,53 +144,54 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
 
     /* DMA piece q covers tile rows 8q..8q+7; this lane fills physical chunk (lane & 7)
      * of row 8q + (lane >> 3) with logical chunk phys ^ swizzle(row). */
-    const float *a_src[T::CHA], *w_src[T::CHW];
+    const char *a_src[T::CHA], *w_src[T::CHW];
     int a_k[T::CHA];
 #pragma unroll
     for (int i = 0; i < T::CHA; ++i) {
         const int r = 8 * (wave * T::CHA + i) + (lane >> 3);
-        const int kc = 4 * ((lane & 7) ^ ((r >> 1) & 7));
-        a_k[i] = kc;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);   /* logical 16-byte chunk of the row's K step */
+        a_k[i] = 4 * chunk;
         const int m = min(m0 + r, p.M - 1);
         if (AMODE == A_ROWS) {
-            a_src[i] = p.A + (size_t)m * p.K + kc;
+            a_src[i] = static_cast<const char *>(p.A) + (size_t)m * p.K * ES + 16 * chunk;
         } else {
             const int np = p.grid * p.grid;
             const int b = m / np, pp = m - b * np;
             const int oh = pp / p.grid, ow = pp - oh * p.grid;
-            a_src[i] = p.A + ((size_t)b * p.chans * p.img + (size_t)oh * p.patch) * p.img +
-                       (size_t)ow * p.patch;
+            a_src[i] = reinterpret_cast<const char *>(
+                static_cast<const float *>(p.A) + ((size_t)b * p.chans * p.img + (size_t)oh * p.patch) * p.img +
+                (size_t)ow * p.patch);
         }
     }
 #pragma unroll
     for (int i = 0; i < T::CHW; ++i) {
         const int r = 8 * (wave * T::CHW + i) + (lane >> 3);
-        const int kc = 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         int n = n0 + r;
         if (NGUARD)
             n = min(n, p.N - 1);
-        w_src[i] = p.W + (size_t)n * p.K + kc;
+        w_src[i] = static_cast<const char *>(p.W) + (size_t)n * p.K * ES + 16 * chunk;
     }
 
-    auto dma = [&](int stage, int k0) {
+    auto dma = [&](int stage, int kt) { /* K step kt: 128 bytes of every operand row */
         float *As = smem + stage * T::STAGE_F, *Ws = As + BM * BK;
 #pragma unroll
         for (int i = 0; i < T::CHA; ++i) {
-            const float *ap;
+            const char *ap;
             if (AMODE == A_ROWS) {
-                ap = a_src[i] + k0;
+                ap = a_src[i] + (size_t)kt * 128;
             } else {
                 /* im2row on load: k = (ic, kh, kw); 4 consecutive kw are contiguous. */
-                const int k = k0 + a_k[i], pp2 = p.patch * p.patch;
+                const int k = kt * BK + a_k[i], pp2 = p.patch * p.patch;
                 const int ic = k / pp2, rem = k - ic * pp2;
                 const int kh = rem / p.patch, kw = rem - kh * p.patch;
-                ap = a_src[i] + ((size_t)ic * p.img + kh) * p.img + kw;
+                ap = a_src[i] + (((size_t)ic * p.img + kh) * p.img + kw) * 4;
             }
             __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(As + (wave * T::CHA + i) * 8 * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < T::CHW; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + k0),
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (size_t)kt * 128),
                                              (lptr_t)(Ws + (wave * T::CHW + i) * 8 * BK), 16, 0, 0);
     };
 
@@ -219,23 +229,32 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
 #pragma unroll
         for (int j = 0; j < JT; ++j)
             b[j] = *reinterpret_cast<const f32x4 *>(w_base + j * 32 * BK + koff[kk]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
+        if (BF16IN) {
 #pragma unroll
             for (int i = 0; i < IT; ++i)
 #pragma unroll
                 for (int j = 0; j < JT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < IT; ++i)
+#pragma unroll
+                    for (int j = 0; j < JT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
     };
 
-    const int nk = p.K / BK;
+    const int nk = p.K / KE;
     dma(0, 0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk)
-            dma(cur ^ 1, (kt + 1) * BK);
+            dma(cur ^ 1, kt + 1);
         const float *As = smem + cur * T::STAGE_F, *Ws = As + BM * BK;
         const float *a_base = As + (wm * 32 * IT + lr) * BK;
         const float *w_base = Ws + (wn * 32 * JT + lr) * BK;
@@ -274,7 +293,10 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
                     v = p.R[orow * p.N + col] + v;
                 if (EPI == EPI_PATCH)
                     v = v + posrow[col];
-                p.C[orow * p.N + col] = v;
+                if (BF16OUT)
+                    static_cast<__bf16 *>(p.C)[orow * p.N + col] = (__bf16)v;
+                else
+                    static_cast<float *>(p.C)[orow * p.N + col] = v;
             }
         }
     }
@@ -291,19 +313,19 @@ __global__ void cls_rows_kernel(const float *cls, const float *pos, float *token
     tokens[(size_t)b * tokens_per_image * E + e] = cls[e] + pos[e];
 }
 
-template <class T, int AMODE, int EPI, bool NGUARD>
+template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false>
 int launch_tile(hipStream_t st, GemmParams p)
 {
     static bool attr_set = false; /* per instantiation; benign race (idempotent) */
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<T, AMODE, EPI, NGUARD>,
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS));
         attr_set = true;
     }
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = (p.N + T::BN - 1) / T::BN;
-    hipLaunchKernelGGL((gemm_f32_kernel<T, AMODE, EPI, NGUARD>), dim3(p.mtiles * p.ntiles), dim3(T::NT),
-                       T::LDS, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT>), dim3(p.mtiles * p.ntiles),
+                       dim3(T::NT), T::LDS, st, p);
     VH_LAUNCH_CHECK("gemm_f32_kernel");
     return 0;
 }
@@ -375,6 +397,76 @@ extern "C" int vh_launch_linear(vh_stream_t s, float *output, const float *weigh
     if (residual)
         return launch<A_ROWS, EPI_RESID>(st, p, colA >= 2048 ? 1 : 0);
     return launch<A_ROWS, EPI_NONE>(st, p, wide ? 4 : 0);
+}
+
+namespace {
+
+/* bf16 operands, fp32 accumulate.  Tile choice: these launches are bandwidth-bound
+ * (the bf16 MFMA is 16x the fp32 one), so they use the 256x256 / 16-wave tile for the
+ * highest operand reuse per byte when N allows, else 128x128 / 8 waves. */
+template <int EPI, bool BF16OUT>
+int launch_bf16(hipStream_t st, const GemmParams &p)
+{
+    int cfg = cfg_override();
+    if (cfg < 0)
+        cfg = (p.N % 256 == 0 && p.M >= 4096) ? 4 : 0;
+    if ((cfg == 3 || cfg == 4 || cfg == 6) && p.N % 256 != 0)
+        cfg = 0;
+    switch (cfg) {
+    case 1: return launch_tile<Tile1, A_ROWS, EPI, false, true, BF16OUT>(st, p);
+    case 2: return launch_tile<Tile2, A_ROWS, EPI, false, true, BF16OUT>(st, p);
+    case 3: return launch_tile<Tile3, A_ROWS, EPI, false, true, BF16OUT>(st, p);
+    case 4: return launch_tile<Tile4, A_ROWS, EPI, false, true, BF16OUT>(st, p);
+    default: return launch_tile<Tile0, A_ROWS, EPI, false, true, BF16OUT>(st, p);
+    }
+}
+
+__global__ void convert_bf16_kernel(const float *__restrict__ in, __bf16 *__restrict__ out, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + i);
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<bf16x4 *>(out + i) = o;
+    } else {
+        for (size_t k = i; k < n; ++k)
+            out[k] = (__bf16)in[k];
+    }
+}
+
+} // namespace
+
+extern "C" int vh_launch_convert_bf16(vh_stream_t s, const float *input, void *output, size_t count)
+{
+    if (!input || !output || count == 0)
+        return vh_fail(1, "vh_launch_convert_bf16: bad argument");
+    const size_t threads = (count + 3) / 4;
+    hipLaunchKernelGGL(convert_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       input, static_cast<__bf16 *>(output), count);
+    VH_LAUNCH_CHECK("convert_bf16_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_linear_bf16(vh_stream_t s, void *output, int output_bf16, const void *weight,
+                                     const void *input, const float *bias, int rowA, int colA, int colB,
+                                     int doGelu, const float *residual)
+{
+    if (!output || !weight || !input || !bias)
+        return vh_fail(1, "vh_launch_linear_bf16: null pointer argument");
+    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % 64 != 0 || colB % 128 != 0)
+        return vh_fail(1, "vh_launch_linear_bf16: needs colA %% 64 == 0 and colB %% 128 == 0 (%d,%d,%d)", rowA, colA, colB);
+    if ((doGelu && residual) || (residual && output_bf16))
+        return vh_fail(1, "vh_launch_linear_bf16: unsupported epilogue combination");
+    GemmParams p = {};
+    p.A = input; p.W = weight; p.bias = bias; p.R = residual; p.C = output;
+    p.M = rowA; p.N = colB; p.K = colA;
+    hipStream_t st = (hipStream_t)s;
+    if (doGelu)
+        return output_bf16 ? launch_bf16<EPI_GELU, true>(st, p) : launch_bf16<EPI_GELU, false>(st, p);
+    if (residual)
+        return launch_bf16<EPI_RESID, false>(st, p);
+    return output_bf16 ? launch_bf16<EPI_NONE, true>(st, p) : launch_bf16<EPI_NONE, false>(st, p);
 }
 
 extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const float *conv_w,

@@ -35,11 +35,11 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 /* NV = 16-byte chunks per lane; handles embed_dim <= 256*NV, embed_dim % 4 == 0. */
-template <int NV>
+template <int NV, bool OUTBF16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta,
-                                                        float *__restrict__ out, int rows, int E,
+                                                        void *__restrict__ out, int rows, int E,
                                                         long in_stride, long out_stride, double eps)
 {
     const int lane = threadIdx.x & 63;
@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
-    f32x4 *dst = reinterpret_cast<f32x4 *>(out + (size_t)row * out_stride);
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(out) + (size_t)row * out_stride);
+    bf16x4 *dst16 = reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(out) + (size_t)row * out_stride);
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
         const int idx = c * 64 + lane;
@@ -80,7 +82,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 y[e] = (x[c][e] - mean) * inv_std * g[e] + bb[e];
-            dst[idx] = y;
+            if (OUTBF16) { /* the only consumer is a bf16-operand GEMM: round once, here */
+                bf16x4 y16 = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+                dst16[idx] = y16;
+            } else {
+                dst[idx] = y;
+            }
         }
     }
 }
@@ -132,9 +139,9 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_kernel(const float *__rest
 
 } // namespace
 
-extern "C" int vh_launch_layer_norm(vh_stream_t s, const float *input, const float *weight,
-                                    const float *bias, float *output, int rows, int embed_dim,
-                                    long in_row_stride, long out_row_stride, double eps)
+static int launch_layer_norm(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                             void *output, int out_bf16, int rows, int embed_dim, long in_row_stride,
+                             long out_row_stride, double eps)
 {
     if (!input || !weight || !bias || !output)
         return vh_fail(1, "vh_launch_layer_norm: null pointer argument");
@@ -146,9 +153,15 @@ extern "C" int vh_launch_layer_norm(vh_stream_t s, const float *input, const flo
     hipStream_t st = (hipStream_t)s;
     const dim3 grid((rows + 3) / 4), block(256);
     const int nv = (embed_dim / 4 + 63) / 64;
-#define VH_LN(NV)                                                                              \
-    hipLaunchKernelGGL((layernorm_kernel<NV>), grid, block, 0, st, input, weight, bias, output, \
-                       rows, embed_dim, in_row_stride, out_row_stride, eps)
+#define VH_LN(NV)                                                                                   \
+    do {                                                                                            \
+        if (out_bf16)                                                                               \
+            hipLaunchKernelGGL((layernorm_kernel<NV, true>), grid, block, 0, st, input, weight, bias, \
+                               output, rows, embed_dim, in_row_stride, out_row_stride, eps);         \
+        else                                                                                        \
+            hipLaunchKernelGGL((layernorm_kernel<NV, false>), grid, block, 0, st, input, weight, bias, \
+                               output, rows, embed_dim, in_row_stride, out_row_stride, eps);         \
+    } while (0)
     if (nv <= 3) VH_LN(3);
     else if (nv <= 4) VH_LN(4);
     else if (nv <= 5) VH_LN(5);
@@ -156,6 +169,22 @@ extern "C" int vh_launch_layer_norm(vh_stream_t s, const float *input, const flo
 #undef VH_LN
     VH_LAUNCH_CHECK("layernorm_kernel");
     return 0;
+}
+
+extern "C" int vh_launch_layer_norm(vh_stream_t s, const float *input, const float *weight,
+                                    const float *bias, float *output, int rows, int embed_dim,
+                                    long in_row_stride, long out_row_stride, double eps)
+{
+    return launch_layer_norm(s, input, weight, bias, output, 0, rows, embed_dim, in_row_stride,
+                             out_row_stride, eps);
+}
+
+extern "C" int vh_launch_layer_norm_bf16(vh_stream_t s, const float *input, const float *weight,
+                                         const float *bias, void *output, int rows, int embed_dim,
+                                         long in_row_stride, long out_row_stride, double eps)
+{
+    return launch_layer_norm(s, input, weight, bias, output, 1, rows, embed_dim, in_row_stride,
+                             out_row_stride, eps);
 }
 
 extern "C" int vh_launch_softmax(vh_stream_t s, const float *input, float *output, int rows,

@@ -33,7 +33,8 @@ EXPORTS = [
     "vit_config_preset", "vit_config_tokens", "vit_config_num_tensors", "vit_config_tensor_size",
     "ViT_opencl", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
     "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
-    "vit_hip_profile_enable", "vit_hip_profile_read",
+    "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_create_ex", "vit_hip_precision",
+    "vh_launch_convert_bf16", "vh_launch_layer_norm_bf16", "vh_launch_linear_bf16", "vh_launch_attention_bf16",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
     "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
 ]
@@ -131,6 +132,12 @@ def lib() -> C.CDLL:
     L.ViT_opencl.argtypes = [C.POINTER(ImageData), C.POINTER(Network), C.POINTER(f32p)]
     L.ViT_opencl.restype = None
     L.vit_hip_create.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i]
+    L.vit_hip_create_ex.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i, i]
+    L.vit_hip_precision.argtypes = [voidp]
+    L.vh_launch_convert_bf16.argtypes = [voidp, voidp, voidp, sz]
+    L.vh_launch_layer_norm_bf16.argtypes = [voidp] + [voidp] * 4 + [i, i, C.c_long, C.c_long, C.c_double]
+    L.vh_launch_linear_bf16.argtypes = [voidp, voidp, i, voidp, voidp, voidp, i, i, i, i, voidp]
+    L.vh_launch_attention_bf16.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vit_hip_destroy.argtypes = [voidp]
     L.vit_hip_destroy.restype = None
     L.vit_hip_forward.argtypes = [voidp, C.POINTER(ImageData), i, f32p, C.POINTER(f32p)]
@@ -253,14 +260,16 @@ class DeviceBuffer:
 class ViTHip:
     """Resident-weights context (vit_hip_create / forward / destroy)."""
 
-    def __init__(self, cfg: VitConfig, weights: list[np.ndarray], device: int = 0, max_batch: int = 64):
+    def __init__(self, cfg: VitConfig, weights: list[np.ndarray], device: int = 0, max_batch: int = 64,
+                 precision: str = "f32"):
         self.cfg = cfg
         self.L = lib()
         self._weights = weights  # keep host arrays alive during create
         self.ctx = voidp()
-        rc = self.L.vit_hip_create(C.byref(self.ctx), C.byref(cfg), networks(weights), len(weights),
-                                   device, max_batch)
-        check(rc, "vit_hip_create")
+        self.precision = precision
+        rc = self.L.vit_hip_create_ex(C.byref(self.ctx), C.byref(cfg), networks(weights), len(weights),
+                                      device, max_batch, {"f32": 0, "bf16": 1}[precision])
+        check(rc, "vit_hip_create_ex")
         self.max_batch = max_batch
         self.tokens = tokens(cfg)
 
