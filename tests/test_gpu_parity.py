@@ -88,7 +88,7 @@ def test_linear_rejects_bad_arguments(pkg, device):
     assert L.vh_launch_linear(None, d.ptr, d.ptr, d.ptr, d.ptr, 4, 32, 8, 1, d.ptr) != 0  # gelu + residual
 
 
-@pytest.mark.parametrize("n_images,tokens", [(1, 197), (3, 197), (2, 5), (1, 33), (2, 64)])
+@pytest.mark.parametrize("n_images,tokens", [(1, 197), (3, 197), (2, 5), (1, 33), (2, 64), (3, 1), (1, 208), (300, 7)])
 def test_attention_vs_oracle(pkg, device, oracle, n_images, tokens):
     E = 768
     qkv = oracle.synth_fill(n_images * tokens * 3 * E, 17 + tokens, 1.5, 0.0).reshape(n_images * tokens, 3 * E)
@@ -115,11 +115,12 @@ def test_attention_rejects_unsupported_shapes(pkg, device):
     L = pkg.lib()
     d = pkg.DeviceBuffer(16)
     assert L.vh_launch_attention(None, d.ptr, d.ptr, 1, 257, 1280, 16) != 0   # head_dim 80
-    assert L.vh_launch_attention(None, d.ptr, d.ptr, 1, 257, 768, 12) != 0    # tokens > 224
+    assert L.vh_launch_attention(None, d.ptr, d.ptr, 1, 257, 768, 12) != 0    # three K/V buffers no longer fit LDS
     assert b"tokens=257" in L.vh_last_error()
+    assert L.vh_launch_attention(None, d.ptr, d.ptr, 0, 197, 768, 12) != 0    # empty batch
 
 
-@pytest.mark.parametrize("rows,length", [(1, 1000), (7, 1000), (3, 5), (2, 2048)])
+@pytest.mark.parametrize("rows,length", [(1, 1000), (7, 1000), (3, 5), (2, 2048), (4, 1)])
 def test_softmax_vs_oracle(pkg, device, oracle, rows, length):
     x = oracle.synth_fill(rows * length, 7 + length, 4.0, 1.0).reshape(rows, length)
     d_x, d_y = _dev(pkg, x), pkg.DeviceBuffer(rows * length)
@@ -192,6 +193,24 @@ def test_model_batch_position_independence(pkg, model):
     out, probs = model.forward(many)
     assert np.array_equal(out[:5], base) and np.array_equal(out[5:10], base) and np.array_equal(out[10], base[0])
     assert np.isfinite(probs).all()
+
+
+def test_forward_rejects_empty_and_malformed_batches(pkg, model):
+    """Edge cases at the boundary: n = 0, n beyond the arena, images of the wrong shape.
+    Errors are status codes, never crashes, and the context stays usable."""
+    L, b = pkg.lib(), pkg.binding
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 0, 2)
+    arr = b.image_array(imgs)
+    logits = np.zeros((2, 1000), dtype=np.float32)
+    assert L.vit_hip_forward(model.ctx, arr, 0, b.fptr(logits), None) == 1
+    bad = b.image_array(np.zeros((1, 3, 112, 112), dtype=np.float32))
+    assert L.vit_hip_forward(model.ctx, bad, 1, b.fptr(logits), None) == 5
+    d = pkg.DeviceBuffer(16)
+    assert L.vit_hip_forward_device(model.ctx, d.ptr, model.max_batch + 1, None, None, None) == 1
+    assert L.vit_hip_forward_device(model.ctx, d.ptr, 0, None, None, None) == 1
+    out, _ = model.forward(imgs[:1])                       # still works, n = 1
+    assert np.isfinite(out).all()
 
 
 def test_dropin_symbol_matches_extended_api(pkg, device, weights, golden_full):
