@@ -234,17 +234,28 @@ def main() -> None:
         fc1_ms, fc1_cnt = prof["fc1_gemm"]
         fc1_flops_per_launch = 2.0 * B * tokens * cfg.embed_dim * cfg.mlp_hidden
         achieved = fc1_flops_per_launch / (fc1_ms / fc1_cnt * 1e-3) / 1e12
-        peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0   # dense bf16 MFMA, same guide
+        # fp32 products are formed on the bf16 cores from an exact 3-way split (6 bf16 MFMAs per
+        # product block, gemm_mfma.hip SPLIT3), unless VIT_HIP_GEMM_FP32=native selects the fp32 MFMA.
+        native = os.environ.get("VIT_HIP_GEMM_FP32", "split3").startswith("n")
+        if args.dtype != "f32":
+            peak_tf, peak_note = 2500.0, "dense bf16 MFMA"
+        elif native:
+            peak_tf, peak_note = PEAK_F32_MFMA_TFLOPS, "native fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+        else:
+            peak_tf, peak_note = 2500.0 / 6.0, ("dense bf16 MFMA peak / 6: six bf16 MFMAs per fp32-equivalent "
+                                                "product block; the native fp32 MFMA peak is 157.3")
         # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes
         # (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); bench.py cannot collect PMCs itself.
         traffic, traffic_src = None, None
         pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if pmc.exists() and B == 512 and args.dtype == "f32":
+        if pmc.exists() and B == 512 and args.dtype == "f32" and not native and "split3" in pmc.read_text():
             traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
             traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, B=512)"
         roofline = {"bound": "mfma",
-                    "kernel": "gemm_f32_kernel<Tile<256,256,4,4>,A_ROWS,EPI_GELU,false> (fc1: M=%d N=%d K=%d)" %
-                    (B * tokens, cfg.mlp_hidden, cfg.embed_dim),
+                    "kernel": "gemm_f32_kernel<...EPI_GELU...> fc1 GEMM (M=%d N=%d K=%d); %s" %
+                    (B * tokens, cfg.mlp_hidden, cfg.embed_dim,
+                     "native fp32 MFMA, Tile<256,256,4,4>" if native else "SPLIT3 on bf16 MFMA, Tile<256,256,2,4>"),
+                    "peak_basis": peak_note,
                     "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(achieved / peak_tf, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
@@ -265,6 +276,9 @@ def main() -> None:
             "config": {"workload": f"ViT-B/16 224x224 fp32 forward (patch-embed..softmax), batch {B} per GPU, "
                                    f"device-resident inputs, random-init weights", "global_batch": world * B,
                        "parallelism": f"dp{world} (batch shards, replicated weights, RCCL gather of logits)"},
+            "gemm_arithmetic": ("bf16 operands, fp32 accumulate" if args.dtype != "f32" else
+                                "fp32 (native fp32 MFMA)" if native else
+                                "fp32 operands split exactly into 3 bf16 parts, 6 bf16 MFMAs per product, fp32 accumulate"),
             "model_tflops": round(total_flops * B * args.steps * world / elapsed / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(total_flops * B * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roofline, "kernels": kernels,

@@ -124,9 +124,22 @@ __device__ __forceinline__ float gelu_exact(float x)
 /* BF16IN: A and W are bf16 (one ds_read_b128 = 8 K elements = one v_mfma_f32_32x32x16_bf16
  * operand, natural k order); otherwise fp32 (four v_mfma_f32_32x32x2_f32 per read).
  * BF16OUT: the result is rounded to bf16 (it feeds the next bf16 GEMM and nothing else). */
-template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false>
+/* SPLIT3 (fp32 operands only): fp32-equivalent products on the bf16 matrix cores.
+ * Each fp32 operand x is split exactly into three bf16 parts, x = x0 + x1 + x2
+ * (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); 3 x 8 significant bits cover
+ * the 24-bit significand), in registers, after the fragment has been read from LDS.
+ * a*b is then the sum of the six partial products of weight >= 2^-16,
+ *     a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1,
+ * each exact in fp32 (8 x 8 bits) and accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
+ * The three dropped products are <= 2^-24 |ab| each: measured, the truncation error of a
+ * K = 768 dot product is 6e-9 of its magnitude, against 1e-6 for the reference's own
+ * sequential fp32 accumulation (tools/split3_numerics.py).  Six bf16 MFMAs (6 x 32 cycles
+ * for a 32x32x16 block) replace eight fp32 MFMAs (8 x 64 cycles): 2.67x the fp32 MFMA
+ * peak, paid for with ~44 VALU instructions per 8-element fragment. */
+template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false, bool SPLIT3 = false>
 __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(const GemmParams p)
 {
+    static_assert(!(SPLIT3 && BF16IN), "SPLIT3 splits fp32 operands");
     constexpr int BM = T::BM, BN = T::BN, IT = T::IT, JT = T::JT;
     constexpr int ES = BF16IN ? 2 : 4;   /* operand element size */
     constexpr int KE = 128 / ES;         /* K elements per step (one 128-byte LDS row) */
@@ -247,6 +260,44 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
         }
     };
 
+    /* x = p0 + p1 + p2 exactly (the subtractions are exact: Sterbenz / aligned bits). */
+    auto split8 = [](const f32x4 &u, const f32x4 &v, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = e < 4 ? u[e] : v[e - 4];
+            const __bf16 h = (__bf16)x;
+            const float r1 = x - (float)h;
+            const __bf16 m = (__bf16)r1;
+            const float r2 = r1 - (float)m;
+            p0[e] = h;
+            p1[e] = m;
+            p2[e] = (__bf16)r2;
+        }
+    };
+    /* One 16-deep k group (two ds_read_b128 per fragment) on the bf16 cores. */
+    auto compute_k16 = [&](const float *a_base, const float *w_base, int s16) {
+        bf16x8 a0[IT], a1[IT], a2[IT], b0[JT], b1[JT], b2[JT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+            split8(*reinterpret_cast<const f32x4 *>(a_base + i * 32 * BK + koff[2 * s16]),
+                   *reinterpret_cast<const f32x4 *>(a_base + i * 32 * BK + koff[2 * s16 + 1]), a0[i], a1[i], a2[i]);
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+            split8(*reinterpret_cast<const f32x4 *>(w_base + j * 32 * BK + koff[2 * s16]),
+                   *reinterpret_cast<const f32x4 *>(w_base + j * 32 * BK + koff[2 * s16 + 1]), b0[j], b1[j], b2[j]);
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) { /* smallest terms first */
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b0[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b2[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
     const int nk = p.K / KE;
     dma(0, 0);
     __syncthreads();
@@ -258,9 +309,15 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
         const float *As = smem + cur * T::STAGE_F, *Ws = As + BM * BK;
         const float *a_base = As + (wm * 32 * IT + lr) * BK;
         const float *w_base = Ws + (wn * 32 * JT + lr) * BK;
+        if (SPLIT3) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk)
-            compute_kk(a_base, w_base, kk);
+            for (int s16 = 0; s16 < BK / 16; ++s16)
+                compute_k16(a_base, w_base, s16);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk)
+                compute_kk(a_base, w_base, kk);
+        }
         __syncthreads();
     }
 
@@ -313,19 +370,19 @@ __global__ void cls_rows_kernel(const float *cls, const float *pos, float *token
     tokens[(size_t)b * tokens_per_image * E + e] = cls[e] + pos[e];
 }
 
-template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false>
+template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false, bool SPLIT3 = false>
 int launch_tile(hipStream_t st, GemmParams p)
 {
     static bool attr_set = false; /* per instantiation; benign race (idempotent) */
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT>,
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT, SPLIT3>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS));
         attr_set = true;
     }
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = (p.N + T::BN - 1) / T::BN;
-    hipLaunchKernelGGL((gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT>), dim3(p.mtiles * p.ntiles),
-                       dim3(T::NT), T::LDS, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT, SPLIT3>),
+                       dim3(p.mtiles * p.ntiles), dim3(T::NT), T::LDS, st, p);
     VH_LAUNCH_CHECK("gemm_f32_kernel");
     return 0;
 }
@@ -350,11 +407,40 @@ int cfg_override()
     return v;
 }
 
+/* fp32 products: the exact 3-way bf16 split on the bf16 cores (default), or the native
+ * fp32 MFMA (VIT_HIP_GEMM_FP32=native).  Both give fp32-level results (same measured
+ * logit parity); the split is ~1.4x faster end to end. */
+bool use_split3()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *env = getenv("VIT_HIP_GEMM_FP32");
+        v = (env && env[0] == 'n') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <int AMODE, int EPI>
 int launch(hipStream_t st, const GemmParams &p, int default_cfg)
 {
     if (p.N % 128 != 0)                      /* ragged N: only the guarded 128x128 tile */
         return launch_tile<Tile0, AMODE, EPI, true>(st, p);
+    if (use_split3()) {
+        /* measured per shape (profiles/): 256x256 with 8 waves of 128x64 (fewest fragment
+         * splits per MFMA) wherever N allows and there is enough work; the N = 768, K = 768
+         * out-projection prefers 128x128 with two workgroups per CU */
+        int c = cfg_override();
+        if (c < 0)
+            c = (p.N % 256 == 0 && p.M >= 4096 && !(EPI == EPI_RESID && p.K < 2048)) ? 3 : 1;
+        if ((c == 3 || c == 4) && p.N % 256 != 0)
+            c = 1;
+        switch (c) {
+        case 0: return launch_tile<Tile0, AMODE, EPI, false, false, false, true>(st, p);
+        case 1: return launch_tile<Tile1, AMODE, EPI, false, false, false, true>(st, p);
+        case 3: return launch_tile<Tile3, AMODE, EPI, false, false, false, true>(st, p);
+        default: return launch_tile<Tile4, AMODE, EPI, false, false, false, true>(st, p);
+        }
+    }
     int cfg = cfg_override() >= 0 ? cfg_override() : default_cfg;
     if ((cfg == 3 || cfg == 4 || cfg == 6) && p.N % 256 != 0)
         cfg = 2;
