@@ -29,6 +29,8 @@ SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 
 def sysfs_sources():
     out = []
+    if os.environ.get("POWER_PROBE_HWMON") != "1":   # hwmon lists every GPU of the host, not only ours
+        return out
     for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
         p = [f for f in (hw + "/power1_average", hw + "/power1_input") if os.path.exists(f)]
         f = hw + "/freq1_input"
@@ -106,7 +108,7 @@ def leg(name, launch, lib, stream):
 def main():
     pkg = graft.load_package()
     lib = pkg.lib()
-    pkg.check(lib.vh_init(0), "vh_init")
+    pkg.binding.check(lib.vh_init(0), "vh_init")
     M, K, N = 197 * 512, 768, 3072
     rng = np.random.default_rng(0)
     a = pkg.DeviceBuffer.from_numpy(rng.standard_normal((M, K), dtype=np.float32))
@@ -115,16 +117,16 @@ def main():
     out = pkg.DeviceBuffer(M * N)
     a16, w16 = pkg.DeviceBuffer(M * K // 2), pkg.DeviceBuffer(N * K // 2)
     stream = C.c_void_p()
-    pkg.check(lib.vh_stream_create(C.byref(stream)), "stream")
-    pkg.check(lib.vh_launch_convert_bf16(stream, a.ptr, a16.ptr, M * K), "cvt")
-    pkg.check(lib.vh_launch_convert_bf16(stream, w.ptr, w16.ptr, N * K), "cvt")
+    pkg.binding.check(lib.vh_stream_create(C.byref(stream)), "stream")
+    pkg.binding.check(lib.vh_launch_convert_bf16(stream, a.ptr, a16.ptr, M * K), "cvt")
+    pkg.binding.check(lib.vh_launch_convert_bf16(stream, w.ptr, w16.ptr, N * K), "cvt")
     print(f"power sources: {sysfs_sources() or 'rocm-smi'}", flush=True)
 
     def f32():
-        pkg.check(lib.vh_launch_linear(stream, out.ptr, w.ptr, a.ptr, b.ptr, M, K, N, 1, None), "linear")
+        pkg.binding.check(lib.vh_launch_linear(stream, out.ptr, w.ptr, a.ptr, b.ptr, M, K, N, 1, None), "linear")
 
     def b16():
-        pkg.check(lib.vh_launch_linear_bf16(stream, out.ptr, 0, w16.ptr, a16.ptr, b.ptr, M, K, N, 1, None),
+        pkg.binding.check(lib.vh_launch_linear_bf16(stream, out.ptr, 0, w16.ptr, a16.ptr, b.ptr, M, K, N, 1, None),
                   "linear_bf16")
 
     os.environ.pop("VIT_HIP_GEMM_FP32", None)

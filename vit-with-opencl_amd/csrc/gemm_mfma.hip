@@ -41,6 +41,7 @@
 #include "kernelHandler.h"
 #include "vit_kernels.h"
 
+#include <cstdint>
 #include <cstdlib>
 
 namespace {
@@ -119,6 +120,27 @@ __device__ __forceinline__ float gelu_exact(float x)
     s = __builtin_fmaf(s, t, 1.627907038e+00f);
     const float erf_a = copysignf(1.0f - __builtin_amdgcn_exp2f(-(t * s)), a);
     return 0.5f * x * (1.0f + erf_a);
+}
+
+/* Exact 3-way bf16 split of eight fp32 values: x = p0 + p1 + p2 with p0 = bf16(x),
+ * p1 = bf16(x - p0), p2 = bf16(x - p0 - p1); the subtractions are exact (Sterbenz / aligned
+ * bits).  Left to the compiler's own pairing (v_cvt_pk_bf16_f32, part of the subtractions as
+ * v_pk_add_f32; ~5.4 VALU instructions per element): writing the fully packed 4.5-instruction
+ * form out with inline asm measured 3 % SLOWER end to end (hazard s_nops, no freedom to
+ * interleave with the MFMAs). */
+__device__ __forceinline__ void split8(const f32x4 &u, const f32x4 &v, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? u[e] : v[e - 4];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        p0[e] = h;
+        p1[e] = m;
+        p2[e] = (__bf16)r2;
+    }
 }
 
 /* BF16IN: A and W are bf16 (one ds_read_b128 = 8 K elements = one v_mfma_f32_32x32x16_bf16
@@ -260,20 +282,6 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
         }
     };
 
-    /* x = p0 + p1 + p2 exactly (the subtractions are exact: Sterbenz / aligned bits). */
-    auto split8 = [](const f32x4 &u, const f32x4 &v, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = e < 4 ? u[e] : v[e - 4];
-            const __bf16 h = (__bf16)x;
-            const float r1 = x - (float)h;
-            const __bf16 m = (__bf16)r1;
-            const float r2 = r1 - (float)m;
-            p0[e] = h;
-            p1[e] = m;
-            p2[e] = (__bf16)r2;
-        }
-    };
     /* One 16-deep k group (two ds_read_b128 per fragment) on the bf16 cores. */
     auto compute_k16 = [&](const float *a_base, const float *w_base, int s16) {
         bf16x8 a0[IT], a1[IT], a2[IT], b0[JT], b1[JT], b2[JT];
@@ -359,6 +367,225 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
     }
 }
 
+/* Operand staging shared by the 16x16x32 kernel below: per-lane source addresses of the
+ * 8-row LDS-DMA pieces (same LDS image as gemm_f32_kernel: 128-byte rows, chunk c of row r
+ * at c ^ ((r >> 1) & 7)). */
+template <class T, int AMODE, int ES>
+struct Staging {
+    const char *a_src[T::CHA], *w_src[T::CHW];
+    int a_k[T::CHA];
+
+    __device__ __forceinline__ void init(const GemmParams &p, int m0, int n0, int wave, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < T::CHA; ++i) {
+            const int r = 8 * (wave * T::CHA + i) + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            a_k[i] = 4 * chunk;
+            const int m = min(m0 + r, p.M - 1);
+            if (AMODE == A_ROWS) {
+                a_src[i] = static_cast<const char *>(p.A) + (size_t)m * p.K * ES + 16 * chunk;
+            } else {
+                const int np = p.grid * p.grid;
+                const int b = m / np, pp = m - b * np;
+                const int oh = pp / p.grid, ow = pp - oh * p.grid;
+                a_src[i] = reinterpret_cast<const char *>(
+                    static_cast<const float *>(p.A) + ((size_t)b * p.chans * p.img + (size_t)oh * p.patch) * p.img +
+                    (size_t)ow * p.patch);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < T::CHW; ++i) {
+            const int r = 8 * (wave * T::CHW + i) + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            w_src[i] = static_cast<const char *>(p.W) + (size_t)(n0 + r) * p.K * ES + 16 * chunk;
+        }
+    }
+
+    __device__ __forceinline__ void dma(const GemmParams &p, float *smem, int stage, int kt, int wave) const
+    {
+        float *As = smem + stage * T::STAGE_F, *Ws = As + T::BM * BK;
+#pragma unroll
+        for (int i = 0; i < T::CHA; ++i) {
+            const char *ap;
+            if (AMODE == A_ROWS) {
+                ap = a_src[i] + (size_t)kt * 128;
+            } else {
+                const int k = kt * BK + a_k[i], pp2 = p.patch * p.patch;
+                const int ic = k / pp2, rem = k - ic * pp2;
+                const int kh = rem / p.patch, kw = rem - kh * p.patch;
+                ap = a_src[i] + (((size_t)ic * p.img + kh) * p.img + kw) * 4;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(As + (wave * T::CHA + i) * 8 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < T::CHW; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (size_t)kt * 128),
+                                             (lptr_t)(Ws + (wave * T::CHW + i) * 8 * BK), 16, 0, 0);
+    }
+};
+
+/* The same GEMM on v_mfma_f32_16x16x32_bf16 (SPLIT3 for fp32 operands, or bf16 operands).
+ * Under an MFMA-dense load the chip holds a higher clock on the 16x16x32 shape than on
+ * 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7), so cycles per FLOP do not decide.
+ * The product is formed transposed, D[n][m] = sum_k W[n][k] A[m][k] (W fragment as the
+ * MFMA's A operand), so that a lane ends up with four CONSECUTIVE output columns of one
+ * row: lane l holds out[m = i*16 + (l & 15)][n = j*16 + 4*(l >> 4) + r], r = 0..3, and the
+ * bias, residual, position-embedding reads and the store are one 16-byte access each.
+ * Operand fragment: lane l holds k = 8*(l >> 4) .. +7 of row (l & 15), natural k order. */
+template <class T, int AMODE, int EPI, bool BF16IN, bool BF16OUT>
+__global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel(const GemmParams p)
+{
+    constexpr int BM = T::BM, BN = T::BN;
+    constexpr int IT = BM / T::WM / 16, JT = BN / T::WN / 16;   /* 16x16 blocks per wave */
+    constexpr int IC = IT < 4 ? IT : 4;                          /* A fragments split at a time */
+    constexpr int ES = BF16IN ? 2 : 4;
+    constexpr int KE = 128 / ES;
+    static_assert(!(BF16IN && AMODE == A_PATCH), "im2row loader is fp32 only");
+    static_assert(IT % IC == 0, "row blocks per wave");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tile = xcd_tile(blockIdx.x, p.mtiles * p.ntiles);
+    const int m0 = (tile / p.ntiles) * BM;
+    const int n0 = (tile % p.ntiles) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / T::WN, wn = wave % T::WN, l15 = lane & 15, q = lane >> 4;
+
+    Staging<T, AMODE, ES> stg;
+    stg.init(p, m0, n0, wave, lane);
+
+    f32x4 acc[IT][JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 16 * JT + j * 16 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+            acc[i][j] = bv;
+    }
+
+    /* rows i*16 + l15 (+ multiples of 16) all have (row >> 1) & 7 == l15 >> 1 */
+    const int swz = l15 >> 1;
+    const float *a_lane = smem + (wm * 16 * IT + l15) * BK;
+    const float *w_lane = smem + BM * BK + (wn * 16 * JT + l15) * BK;
+
+
+    auto compute = [&](int stage) {
+        const float *ab = a_lane + stage * T::STAGE_F, *wb = w_lane + stage * T::STAGE_F;
+        if constexpr (BF16IN) {
+            /* 64 bf16 per LDS row = two 32-deep groups; one ds_read_b128 per fragment */
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int ko = 4 * ((4 * g + q) ^ swz);
+                bf16x8 w[JT];
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+                    w[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + ko));
+#pragma unroll
+                for (int i = 0; i < IT; ++i) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(ab + i * 16 * BK + ko));
+#pragma unroll
+                    for (int j = 0; j < JT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a, acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
+            const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
+            bf16x8 w0[JT], w1[JT], w2[JT];
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+                split8(*reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k0),
+                       *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k1), w0[j], w1[j], w2[j]);
+#pragma unroll
+            for (int ih = 0; ih < IT; ih += IC) {
+                bf16x8 a0[IC], a1[IC], a2[IC];
+#pragma unroll
+                for (int ii = 0; ii < IC; ++ii)
+                    split8(*reinterpret_cast<const f32x4 *>(ab + (ih + ii) * 16 * BK + k0),
+                           *reinterpret_cast<const f32x4 *>(ab + (ih + ii) * 16 * BK + k1), a0[ii], a1[ii], a2[ii]);
+#pragma unroll
+                for (int ii = 0; ii < IC; ++ii)
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) { /* smallest terms first */
+                        f32x4 c = acc[ih + ii][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a2[ii], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j], a0[ii], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], a1[ii], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a1[ii], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], a0[ii], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a0[ii], c, 0, 0, 0);
+                        acc[ih + ii][j] = c;
+                    }
+            }
+        }
+    };
+
+    const int nk = p.K / KE;
+    stg.dma(p, smem, 0, 0, wave);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk)
+            stg.dma(p, smem, cur ^ 1, kt + 1, wave);
+        compute(cur);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int row = m0 + wm * 16 * IT + i * 16 + l15;
+        if (row >= p.M)
+            continue;
+        size_t orow = (size_t)row;
+        const float *posrow = nullptr;
+        if (EPI == EPI_PATCH) {
+            const int np = p.grid * p.grid;
+            const int b = row / np, pp = row - b * np;
+            orow = (size_t)b * p.tokens + 1 + pp;
+            posrow = p.pos + (size_t)(1 + pp) * p.N;
+        }
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const int col = n0 + wn * 16 * JT + j * 16 + 4 * q;
+            f32x4 v = acc[i][j];
+            if (EPI == EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = gelu_exact(v[r]);
+            }
+            if (EPI == EPI_RESID)
+                v = *reinterpret_cast<const f32x4 *>(p.R + orow * p.N + col) + v;
+            if (EPI == EPI_PATCH)
+                v = v + *reinterpret_cast<const f32x4 *>(posrow + col);
+            if (BF16OUT) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(p.C) + orow * p.N + col) = o;
+            } else {
+                *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + orow * p.N + col) = v;
+            }
+        }
+    }
+}
+
+template <class T, int AMODE, int EPI, bool BF16IN, bool BF16OUT>
+int launch_mf16(hipStream_t st, GemmParams p)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, BF16IN, BF16OUT>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS));
+        attr_set = true;
+    }
+    p.mtiles = (p.M + T::BM - 1) / T::BM;
+    p.ntiles = p.N / T::BN;
+    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, BF16IN, BF16OUT>), dim3(p.mtiles * p.ntiles),
+                       dim3(T::NT), T::LDS, st, p);
+    VH_LAUNCH_CHECK("gemm_mf16_kernel");
+    return 0;
+}
+
 /* Token 0 of every image: class token + pos_embed[0] (ViT_seq.c:90-93,114-117). */
 __global__ void cls_rows_kernel(const float *cls, const float *pos, float *tokens, int n_images,
                                 int tokens_per_image, int E)
@@ -396,13 +623,14 @@ using Tile3 = Tile<256, 256, 2, 4>; /*  8 waves of 128x64                      *
 using Tile4 = Tile<256, 256, 4, 4>; /* 16 waves of 64x64                       */
 using Tile5 = Tile<256, 128, 4, 4>; /* 16 waves of 64x32                       */
 using Tile6 = Tile<128, 256, 2, 4>; /*  8 waves of 64x64                       */
+using Tile7 = Tile<256, 256, 2, 2>; /*  4 waves of 128x128, one per SIMD       */
 
 int cfg_override()
 {
     static int v = -2;
     if (v == -2) {
         const char *env = getenv("VIT_HIP_GEMM_CFG");
-        v = (env && env[0] >= '0' && env[0] <= '6') ? env[0] - '0' : -1;
+        v = (env && env[0] >= '0' && env[0] <= '7') ? env[0] - '0' : -1;
     }
     return v;
 }
@@ -420,6 +648,21 @@ bool use_split3()
     return v == 1;
 }
 
+bool mfma_shape16()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *env = getenv("VIT_HIP_GEMM_MFMA");   /* "32": the 32x32x16 shape */
+        v = (env && env[0] == '3' && env[1] == '2') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+bool aligned16(const GemmParams &p)
+{
+    return (((uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.R | (uintptr_t)p.pos) & 15) == 0;
+}
+
 template <int AMODE, int EPI>
 int launch(hipStream_t st, const GemmParams &p, int default_cfg)
 {
@@ -432,16 +675,24 @@ int launch(hipStream_t st, const GemmParams &p, int default_cfg)
         int c = cfg_override();
         if (c < 0)
             c = (p.N % 256 == 0 && p.M >= 4096 && !(EPI == EPI_RESID && p.K < 2048)) ? 3 : 1;
-        if ((c == 3 || c == 4) && p.N % 256 != 0)
+        if ((c == 3 || c == 4 || c == 7) && p.N % 256 != 0)
             c = 1;
+        if (mfma_shape16() && aligned16(p)) {
+            switch (c) {
+            case 1: return launch_mf16<Tile1, AMODE, EPI, false, false>(st, p);
+            case 7: return launch_mf16<Tile7, AMODE, EPI, false, false>(st, p);
+            default: return launch_mf16<Tile3, AMODE, EPI, false, false>(st, p);
+            }
+        }
         switch (c) {
         case 0: return launch_tile<Tile0, AMODE, EPI, false, false, false, true>(st, p);
         case 1: return launch_tile<Tile1, AMODE, EPI, false, false, false, true>(st, p);
         case 3: return launch_tile<Tile3, AMODE, EPI, false, false, false, true>(st, p);
+        case 7: return launch_tile<Tile7, AMODE, EPI, false, false, false, true>(st, p);
         default: return launch_tile<Tile4, AMODE, EPI, false, false, false, true>(st, p);
         }
     }
-    int cfg = cfg_override() >= 0 ? cfg_override() : default_cfg;
+    int cfg = cfg_override() >= 0 && cfg_override() <= 6 ? cfg_override() : default_cfg;
     if ((cfg == 3 || cfg == 4 || cfg == 6) && p.N % 256 != 0)
         cfg = 2;
     switch (cfg) {
@@ -496,8 +747,17 @@ int launch_bf16(hipStream_t st, const GemmParams &p)
     int cfg = cfg_override();
     if (cfg < 0)
         cfg = (p.N % 256 == 0 && p.M >= 4096) ? 4 : 0;
-    if ((cfg == 3 || cfg == 4 || cfg == 6) && p.N % 256 != 0)
+    if ((cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7) && p.N % 256 != 0)
         cfg = 0;
+    if (mfma_shape16() && aligned16(p)) {
+        switch (cfg) {
+        case 0: return launch_mf16<Tile0, A_ROWS, EPI, true, BF16OUT>(st, p);
+        case 1: return launch_mf16<Tile1, A_ROWS, EPI, true, BF16OUT>(st, p);
+        case 3: return launch_mf16<Tile3, A_ROWS, EPI, true, BF16OUT>(st, p);
+        case 7: return launch_mf16<Tile7, A_ROWS, EPI, true, BF16OUT>(st, p);
+        default: return launch_mf16<Tile4, A_ROWS, EPI, true, BF16OUT>(st, p);
+        }
+    }
     switch (cfg) {
     case 1: return launch_tile<Tile1, A_ROWS, EPI, false, true, BF16OUT>(st, p);
     case 2: return launch_tile<Tile2, A_ROWS, EPI, false, true, BF16OUT>(st, p);
