@@ -248,13 +248,17 @@ def main() -> None:
         # (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); bench.py cannot collect PMCs itself.
         traffic, traffic_src = None, None
         pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if pmc.exists() and B == 512 and args.dtype == "f32" and not native and "split3" in pmc.read_text():
+        if pmc.exists() and B == 512 and args.dtype == "f32" and not native and "gemm_mf16_kernel" in pmc.read_text():
             traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
             traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, B=512)"
         roofline = {"bound": "mfma",
-                    "kernel": "gemm_f32_kernel<...EPI_GELU...> fc1 GEMM (M=%d N=%d K=%d); %s" %
-                    (B * tokens, cfg.mlp_hidden, cfg.embed_dim,
-                     "native fp32 MFMA, Tile<256,256,4,4>" if native else "SPLIT3 on bf16 MFMA, Tile<256,256,2,4>"),
+                    "kernel": "%s fc1 GEMM (M=%d N=%d K=%d); %s" %
+                    ("gemm_f32_kernel<...EPI_GELU...>" if native or args.dtype != "f32" and False else
+                     "gemm_mf16_kernel<Tile<256,256,2,4>,A_ROWS,EPI_GELU,...>",
+                     B * tokens, cfg.mlp_hidden, cfg.embed_dim,
+                     "native fp32 MFMA (v_mfma_f32_32x32x2_f32), Tile<256,256,4,4>" if native else
+                     "bf16 operands on v_mfma_f32_16x16x32_bf16" if args.dtype != "f32" else
+                     "exact 3-way bf16 split of fp32 operands, 6 x v_mfma_f32_16x16x32_bf16 per block"),
                     "peak_basis": peak_note,
                     "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(achieved / peak_tf, 4), "traffic": traffic,

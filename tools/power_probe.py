@@ -99,7 +99,7 @@ def leg(name, launch, lib, stream):
     pw = [r[0] for r in rows if r[0] is not None]
     ck = [r[1] for r in rows if r[1] is not None]
     fl = 2.0 * 197 * 512 * 768 * 3072
-    print(f"{name:14s} {dt / n * 1e3:7.3f} ms/launch {fl * n / dt / 1e12:7.1f} TFLOP/s | power "
+    print(f"{name:26s} {dt / n * 1e3:7.3f} ms/launch {fl * n / dt / 1e12:7.1f} TFLOP/s | power "
           f"mean {np.mean(pw) if pw else float('nan'):7.1f} W max {max(pw) if pw else float('nan'):7.1f} W | "
           f"sclk mean {np.mean(ck) if ck else float('nan'):7.1f} MHz min {min(ck) if ck else float('nan'):7.1f} "
           f"({len(rows)} samples, source {'hwmon' if s.src else 'rocm-smi'})", flush=True)
@@ -129,11 +129,9 @@ def main():
         pkg.binding.check(lib.vh_launch_linear_bf16(stream, out.ptr, 0, w16.ptr, a16.ptr, b.ptr, M, K, N, 1, None),
                   "linear_bf16")
 
-    os.environ.pop("VIT_HIP_GEMM_FP32", None)
     leg("idle", lambda: time.sleep(0.01), lib, stream)
-    leg("split3", f32, lib, stream)
+    leg("fp32 (" + os.environ.get("VIT_HIP_GEMM_FP32", "split3") + ", mfma " + os.environ.get("VIT_HIP_GEMM_MFMA", "16") + ")", f32, lib, stream)
     leg("bf16 operands", b16, lib, stream)
-    print("(native fp32 MFMA: run again with VIT_HIP_GEMM_FP32=native; the choice is read once per process)")
 
 
 if __name__ == "__main__":
