@@ -97,6 +97,8 @@ def main() -> None:
                     help="f32 = the parity path (default, what `value` is quoted on); bf16 = bf16-operand GEMMs "
                          "(BASELINE config 3; logits ~1e-2 from ViT_seq.c, so never the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=["vit_b_16", "vit_l_16", "vit_h_14"], default="vit_b_16",
+                    help="vit_b_16 is BASELINE.json's metric; the others are the parity-test shapes, timed for DESIGN.md")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (0 = auto)")
     args = ap.parse_args()
 
@@ -119,8 +121,9 @@ def main() -> None:
     # one GPU per rank; VIT_BENCH_DEVICE pins every rank to one card for a gloo rehearsal
     device = int(os.environ.get("VIT_BENCH_DEVICE", comm.local_rank if comm else 0))
 
-    cfg = pkg.preset("vit_b_16")
+    cfg = pkg.preset(args.model)
     tokens = pkg.binding.tokens(cfg)
+    label = {"vit_b_16": "ViT-B/16", "vit_l_16": "ViT-L/16", "vit_h_14": "ViT-H/14"}[args.model]
     B, NC = args.batch, cfg.num_classes
 
     weights = pkg.synth_weights(cfg, 0)
@@ -248,7 +251,7 @@ def main() -> None:
         # (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); bench.py cannot collect PMCs itself.
         traffic, traffic_src = None, None
         pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if pmc.exists() and B == 512 and args.dtype == "f32" and not native and "gemm_mf16_kernel" in pmc.read_text():
+        if pmc.exists() and B == 512 and args.model == "vit_b_16" and args.dtype == "f32" and not native and "gemm_mf16_kernel" in pmc.read_text():
             traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
             traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, B=512)"
         roofline = {"bound": "mfma",
@@ -273,11 +276,11 @@ def main() -> None:
             logits0 = d_logits.to_numpy((B, NC))[0]
         probs0 = d_probs.to_numpy((B, NC))[0]
         out = {
-            "metric": "images/sec ViT-B/16 224x224 bs512", "value": round(value, 2), "unit": "images/sec",
+            "metric": f"images/sec {label} 224x224 bs{B}" if (args.model, B) != ("vit_b_16", 512) else "images/sec ViT-B/16 224x224 bs512", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"ViT-B/16 224x224 fp32 forward (patch-embed..softmax), batch {B} per GPU, "
+            "config": {"workload": f"{label} 224x224 {args.dtype} forward (patch-embed..softmax), batch {B} per GPU, "
                                    f"device-resident inputs, random-init weights", "global_batch": world * B,
                        "parallelism": f"dp{world} (batch shards, replicated weights, RCCL gather of logits)"},
             "gemm_arithmetic": ("bf16 operands, fp32 accumulate" if args.dtype != "f32" else
@@ -289,7 +292,7 @@ def main() -> None:
         }
         if bf16_leg is not None:
             out["bf16_gemm_mode"] = bf16_leg
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "vit_b_16":
             nproc = args.cpu_procs or max(1, min(os.cpu_count() or 1, 16))
             base, ref_logits = cpu_baseline(nproc)
             out["cpu_baseline"] = base

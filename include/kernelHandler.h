@@ -88,6 +88,16 @@ int vh_launch_patch_embed(vh_stream_t s, const float *images, const float *conv_
                           float *tokens, int n_images, int in_chans, int img_size,
                           int patch_size, int embed_dim);
 
+/* The same for patch geometries whose rows cannot be gathered on load (patch % 4 != 0 or
+ * in_chans*patch*patch % 32 != 0 -- ViT-H/14: 3*14*14 = 588): patches are gathered once
+ * into zero-padded rows in `workspace` (vh_patch_embed_workspace() bytes, 16-byte aligned;
+ * 0 for geometries vh_launch_patch_embed takes directly, which then ignores the workspace). */
+size_t vh_patch_embed_workspace(int n_images, int in_chans, int img_size, int patch_size, int embed_dim);
+int vh_launch_patch_embed_ws(vh_stream_t s, const float *images, const float *conv_w,
+                             const float *conv_b, const float *cls_token, const float *pos_embed,
+                             float *tokens, int n_images, int in_chans, int img_size,
+                             int patch_size, int embed_dim, void *workspace, size_t workspace_bytes);
+
 /* Row LayerNorm, y = (x-mean)*inv_std*w + b with var = E[x^2]-mean^2 and
  * inv_std = 1/sqrt(var+eps) (eps added in double, ViT_seq.c:21,135).
  * Replaces layer_norm (ViT_opencl.c:444-482; layerNorm layer_norm.cl:3; CPU

@@ -55,6 +55,7 @@ struct vit_hip_ctx
     float *attn;        /* attention output     [rows][E]   */
     float *qkv;         /* fused Q|K|V          [rows][3E]  */
     float *hid;         /* MLP hidden           [rows][F]   */
+    size_t ws_bytes;    /* size of hid, which doubles as the patch-gather workspace */
     float *cls;         /* normalised CLS rows  [max_batch][E] */
     float *d_logits;    /* [max_batch][classes] */
     float *d_probs;     /* [max_batch][classes] */
@@ -253,7 +254,12 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
     TRY(vh_malloc((void **)&ctx->y, rows * E * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->attn, rows * E * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->qkv, rows * 3 * E * sizeof(float)));
-    TRY(vh_malloc((void **)&ctx->hid, rows * F * sizeof(float)));
+    {   /* patch geometries that need gathered rows (H/14) borrow the MLP hidden buffer, idle at that point */
+        const size_t ws = vh_patch_embed_workspace(max_batch, cfg->in_chans, cfg->img_size, cfg->patch_size, cfg->embed_dim);
+        const size_t hid_bytes = rows * F * sizeof(float);
+        ctx->ws_bytes = ws > hid_bytes ? ws : hid_bytes;
+        TRY(vh_malloc((void **)&ctx->hid, ctx->ws_bytes));
+    }
     TRY(vh_malloc((void **)&ctx->cls, (size_t)max_batch * E * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->d_logits, (size_t)max_batch * NC * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->d_probs, (size_t)max_batch * NC * sizeof(float)));
@@ -288,8 +294,8 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     float **w = ctx->w;
 
     /* patch embedding + class token + position embedding (ViT_seq.c:437-443) */
-    OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n,
-                                                 c->in_chans, c->img_size, c->patch_size, E));
+    OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_ws(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n, c->in_chans,
+                                                    c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
 
     for (int l = 0; l < c->depth && ctx->precision == VIT_PRECISION_BF16_GEMM; ++l) {
         /* bf16 GEMM operands: y, attn and hid hold bf16 (same allocations, half used);

@@ -37,6 +37,8 @@
 #include "kernelHandler.h"
 #include "vit_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int HD = 64;                    /* head dim this kernel is specialised for */
@@ -328,12 +330,18 @@ static int launch_attention(vh_stream_t s, const float *qkv, void *output, int o
 {
     if (!qkv || !output)
         return vh_fail(1, "vh_launch_attention: null pointer argument");
-    if (n_images <= 0 || tokens <= 0 || num_heads <= 0 || embed_dim != num_heads * HD)
-        return vh_fail(1, "vh_launch_attention: needs head_dim == %d (embed=%d heads=%d)", HD,
-                       embed_dim, num_heads);
-    if (tokens > MAX_ROWS)
-        return vh_fail(1, "vh_launch_attention: tokens=%d exceeds the %d whose three K/V buffers fit a CU's LDS",
-                       tokens, MAX_ROWS);
+    if (n_images <= 0 || tokens <= 0 || num_heads <= 0 || embed_dim <= 0)
+        return vh_fail(1, "vh_launch_attention: non-positive dimension (n=%d tokens=%d embed=%d heads=%d)",
+                       n_images, tokens, embed_dim, num_heads);
+    /* Resident K/V (this file) where one head's K and V fit the LDS three times over;
+     * otherwise the streaming kernel (VIT_HIP_ATTN=tiled forces it, for tests). */
+    static int force_tiled = -1;
+    if (force_tiled < 0) {
+        const char *env = getenv("VIT_HIP_ATTN");
+        force_tiled = (env && env[0] == 't') ? 1 : 0;
+    }
+    if (embed_dim != num_heads * HD || tokens > MAX_ROWS || force_tiled)
+        return vh_attention_tiled(s, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
     hipStream_t st = (hipStream_t)s;
     switch ((tokens + 31) / 32) {
     case 1: return launch<1>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);

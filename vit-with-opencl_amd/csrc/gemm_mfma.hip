@@ -815,10 +815,58 @@ extern "C" int vh_launch_linear_bf16(vh_stream_t s, void *output, int output_bf1
     return output_bf16 ? launch_bf16<EPI_NONE, true>(st, p) : launch_bf16<EPI_NONE, false>(st, p);
 }
 
-extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const float *conv_w,
-                                     const float *conv_b, const float *cls_token,
-                                     const float *pos_embed, float *tokens, int n_images,
-                                     int in_chans, int img_size, int patch_size, int embed_dim)
+namespace {
+
+/* Patch geometries the im2row-on-load GEMM cannot take (patch % 4 != 0 or C*P*P % 32 != 0;
+ * ViT-H/14: 3*14*14 = 588): the patches are gathered once into rows of Kp = roundup(K, 32)
+ * floats, zero-padded, and the weights are padded alike; then it is an ordinary rows GEMM. */
+__global__ void im2row_pad_kernel(const float *__restrict__ images, float *__restrict__ rows, int n_rows, int chans,
+                                  int img, int patch, int grid, int K, int Kp)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n_rows * Kp)
+        return;
+    const int m = (int)(idx / Kp), k = (int)(idx - (size_t)m * Kp);
+    float v = 0.0f;
+    if (k < K) {
+        const int np = grid * grid, b = m / np, pp = m - b * np, oh = pp / grid, ow = pp - oh * grid;
+        const int pp2 = patch * patch, ic = k / pp2, rem = k - ic * pp2, kh = rem / patch, kw = rem - kh * patch;
+        v = images[(((size_t)b * chans + ic) * img + (size_t)oh * patch + kh) * img + (size_t)ow * patch + kw];
+    }
+    rows[idx] = v;
+}
+
+__global__ void pad_rows_kernel(const float *__restrict__ in, float *__restrict__ out, int n_rows, int K, int Kp)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n_rows * Kp)
+        return;
+    const int r = (int)(idx / Kp), k = (int)(idx - (size_t)r * Kp);
+    out[idx] = k < K ? in[(size_t)r * K + k] : 0.0f;
+}
+
+bool patch_direct(int in_chans, int img_size, int patch_size)
+{
+    return patch_size % 4 == 0 && (in_chans * patch_size * patch_size) % BK == 0 && img_size % 4 == 0;
+}
+
+} // namespace
+
+extern "C" size_t vh_patch_embed_workspace(int n_images, int in_chans, int img_size, int patch_size, int embed_dim)
+{
+    if (n_images <= 0 || in_chans <= 0 || img_size <= 0 || patch_size <= 0 || embed_dim <= 0 ||
+        img_size % patch_size != 0 || patch_direct(in_chans, img_size, patch_size))
+        return 0;
+    const size_t grid = img_size / patch_size, K = (size_t)in_chans * patch_size * patch_size;
+    const size_t Kp = (K + BK - 1) / BK * BK;
+    return ((size_t)n_images * grid * grid + (size_t)embed_dim) * Kp * sizeof(float);
+}
+
+extern "C" int vh_launch_patch_embed_ws(vh_stream_t s, const float *images, const float *conv_w,
+                                        const float *conv_b, const float *cls_token,
+                                        const float *pos_embed, float *tokens, int n_images,
+                                        int in_chans, int img_size, int patch_size, int embed_dim,
+                                        void *workspace, size_t workspace_bytes)
 {
     if (!images || !conv_w || !conv_b || !cls_token || !pos_embed || !tokens)
         return vh_fail(1, "vh_launch_patch_embed: null pointer argument");
@@ -826,10 +874,12 @@ extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const f
         img_size % patch_size != 0)
         return vh_fail(1, "vh_launch_patch_embed: bad geometry");
     const int K = in_chans * patch_size * patch_size;
-    if (patch_size % 4 != 0 || K % BK != 0 || img_size % 4 != 0)
-        return vh_fail(1, "vh_launch_patch_embed: patch=%d (K=%d) needs patch%%4==0 and K%%%d==0",
-                       patch_size, K, BK);
     const int grid = img_size / patch_size;
+    const bool direct = patch_direct(in_chans, img_size, patch_size);
+    const size_t need = vh_patch_embed_workspace(n_images, in_chans, img_size, patch_size, embed_dim);
+    if (!direct && (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)))
+        return vh_fail(1, "vh_launch_patch_embed: patch=%d (K=%d) is not a multiple of 4 / %d: this geometry needs "
+                          "vh_launch_patch_embed_ws with %zu bytes of workspace", patch_size, K, BK, need);
 
     GemmParams p = {};
     p.A = images; p.W = conv_w; p.bias = conv_b; p.pos = pos_embed; p.C = tokens;
@@ -842,5 +892,28 @@ extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const f
     hipLaunchKernelGGL(cls_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, st, cls_token,
                        pos_embed, tokens, n_images, p.tokens, embed_dim);
     VH_LAUNCH_CHECK("cls_rows_kernel");
-    return launch<A_PATCH, EPI_PATCH>(st, p, (embed_dim % 256 == 0 && p.M >= 4096) ? 4 : 0);
+    const int cfg = (embed_dim % 256 == 0 && p.M >= 4096) ? 4 : 0;
+    if (direct)
+        return launch<A_PATCH, EPI_PATCH>(st, p, cfg);
+
+    const int Kp = (K + BK - 1) / BK * BK;
+    float *rows = static_cast<float *>(workspace), *wpad = rows + (size_t)p.M * Kp;
+    const size_t n1 = (size_t)p.M * Kp, n2 = (size_t)embed_dim * Kp;
+    hipLaunchKernelGGL(im2row_pad_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, images, rows, p.M,
+                       in_chans, img_size, patch_size, grid, K, Kp);
+    VH_LAUNCH_CHECK("im2row_pad_kernel");
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, conv_w, wpad,
+                       embed_dim, K, Kp);
+    VH_LAUNCH_CHECK("pad_rows_kernel");
+    p.A = rows; p.W = wpad; p.K = Kp;
+    return launch<A_ROWS, EPI_PATCH>(st, p, cfg);
+}
+
+extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const float *conv_w,
+                                     const float *conv_b, const float *cls_token,
+                                     const float *pos_embed, float *tokens, int n_images,
+                                     int in_chans, int img_size, int patch_size, int embed_dim)
+{
+    return vh_launch_patch_embed_ws(s, images, conv_w, conv_b, cls_token, pos_embed, tokens, n_images, in_chans,
+                                    img_size, patch_size, embed_dim, nullptr, 0);
 }

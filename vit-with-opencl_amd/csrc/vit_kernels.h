@@ -6,6 +6,7 @@
 #define VIT_HIP_VIT_KERNELS_H
 
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -14,6 +15,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 int vh_fail(int code, const char *fmt, ...);
 /* Converts a hipError_t into the launcher return convention, recording text. */
 int vh_hip_status(hipError_t e, const char *what);
+
+/* attention_tiled.hip: the shapes the resident-K/V attention kernel does not take. */
+int vh_attention_tiled(void *stream, const float *qkv, void *output, int out_bf16, int n_images, int tokens,
+                       int embed_dim, int num_heads);
 
 #define VH_TRY(expr)                                                           \
     do {                                                                       \

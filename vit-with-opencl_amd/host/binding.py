@@ -35,6 +35,7 @@ EXPORTS = [
     "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_create_ex", "vit_hip_precision",
     "vh_launch_convert_bf16", "vh_launch_layer_norm_bf16", "vh_launch_linear_bf16", "vh_launch_attention_bf16",
+    "vh_patch_embed_workspace", "vh_launch_patch_embed_ws",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
     "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
 ]
@@ -120,6 +121,9 @@ def lib() -> C.CDLL:
     L.vh_d2h.argtypes = [voidp, voidp, sz, voidp]
     L.vh_d2d.argtypes = [voidp, voidp, sz, voidp]
     L.vh_launch_patch_embed.argtypes = [voidp] + [voidp] * 6 + [i] * 5
+    L.vh_launch_patch_embed_ws.argtypes = [voidp] + [voidp] * 6 + [i] * 5 + [voidp, sz]
+    L.vh_patch_embed_workspace.argtypes = [i] * 5
+    L.vh_patch_embed_workspace.restype = sz
     L.vh_launch_layer_norm.argtypes = [voidp] + [voidp] * 4 + [i, i, C.c_long, C.c_long, C.c_double]
     L.vh_launch_linear.argtypes = [voidp] + [voidp] * 4 + [i, i, i, i, voidp]
     L.vh_launch_attention.argtypes = [voidp, voidp, voidp, i, i, i, i]
