@@ -93,7 +93,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "fp8"], default="f32",
                     help="f32 = the parity path (default, what `value` is quoted on); bf16 = bf16-operand GEMMs "
                          "(BASELINE config 3; logits ~1e-2 from ViT_seq.c, so never the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,6 +140,8 @@ def main() -> None:
         pkg.binding.check(L.vh_h2d(d_images.ptr.value + lo * per * 4, chunk.ctypes.data, n * per * 4, None), "vh_h2d")
         pkg.binding.check(L.vh_device_sync(), "sync")
 
+    if args.dtype == "fp8":   # activation ranges from the first images of this rank's batch
+        model.calibrate_fp8_device(d_images.ptr, min(B, 32))
     d_probs = pkg.DeviceBuffer(B * NC)
     use_rccl = comm is not None and comm.backend == "nccl"
     if use_rccl:
@@ -241,7 +243,7 @@ def main() -> None:
         # product block, gemm_mfma.hip SPLIT3), unless VIT_HIP_GEMM_FP32=native selects the fp32 MFMA.
         native = os.environ.get("VIT_HIP_GEMM_FP32", "split3").startswith("n")
         if args.dtype != "f32":
-            peak_tf, peak_note = 2500.0, "dense bf16 MFMA"
+            peak_tf, peak_note = 2500.0, "dense bf16 MFMA (non-scaled fp8 MFMA runs at the same rate)"
         elif native:
             peak_tf, peak_note = PEAK_F32_MFMA_TFLOPS, "native fp32 MFMA (v_mfma_f32_32x32x2_f32)"
         else:
@@ -260,7 +262,8 @@ def main() -> None:
                      "gemm_mf16_kernel<Tile<256,256,2,4>,A_ROWS,EPI_GELU,...>",
                      B * tokens, cfg.mlp_hidden, cfg.embed_dim,
                      "native fp32 MFMA (v_mfma_f32_32x32x2_f32), Tile<256,256,4,4>" if native else
-                     "bf16 operands on v_mfma_f32_16x16x32_bf16" if args.dtype != "f32" else
+                     "bf16 operands on v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16" else
+                     "e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8" if args.dtype == "fp8" else
                      "exact 3-way bf16 split of fp32 operands, 6 x v_mfma_f32_16x16x32_bf16 per block"),
                     "peak_basis": peak_note,
                     "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
@@ -283,7 +286,9 @@ def main() -> None:
             "config": {"workload": f"{label} 224x224 {args.dtype} forward (patch-embed..softmax), batch {B} per GPU, "
                                    f"device-resident inputs, random-init weights", "global_batch": world * B,
                        "parallelism": f"dp{world} (batch shards, replicated weights, RCCL gather of logits)"},
-            "gemm_arithmetic": ("bf16 operands, fp32 accumulate" if args.dtype != "f32" else
+            "gemm_arithmetic": ("bf16 operands, fp32 accumulate" if args.dtype == "bf16" else
+                                "e4m3 operands (per-row weight scales, per-tensor activation scales), fp32 accumulate"
+                                if args.dtype == "fp8" else
                                 "fp32 (native fp32 MFMA)" if native else
                                 "fp32 operands split exactly into 3 bf16 parts, 6 bf16 MFMAs per product, fp32 accumulate"),
             "model_tflops": round(total_flops * B * args.steps * world / elapsed / 1e12, 2),

@@ -78,10 +78,21 @@ void vit_hip_destroy(vit_hip_ctx *ctx);
  * arithmetic, norms and classifier stay fp32.  Its logits differ from ViT_seq.c by
  * ~1e-2 (tests/test_gpu_parity.py states the tolerance), so it is opt-in:
  * vit_hip_create() uses F32 unless $VIT_HIP_PRECISION=bf16. */
-enum { VIT_PRECISION_F32 = 0, VIT_PRECISION_BF16_GEMM = 1 };
+enum { VIT_PRECISION_F32 = 0, VIT_PRECISION_BF16_GEMM = 1, VIT_PRECISION_FP8_GEMM = 2 };
 int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                       int n_tensors, int device, int max_batch, int precision);
 int vit_hip_precision(const vit_hip_ctx *ctx);
+
+/* FP8_GEMM (BASELINE config 5: "fp8 weights (CDNA4 fp8 MFMA)"): the same four matrices as OCP
+ * e4m3 bytes with one scale per output row, their inputs (LayerNorm outputs, attention
+ * output, MLP hidden layer) as e4m3 with one calibrated scale per tensor, products on
+ * v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation; everything else as in BF16_GEMM.
+ * A context created with this precision must be calibrated once on representative images
+ * before the first forward (which fails otherwise): the fp32 path runs over them and
+ * records max |x| of every GEMM input.  Logits differ from ViT_seq.c at the 1e-1 level
+ * (3-bit significands; tools/quant_report.py prints the per-layer error), so: opt-in only. */
+int vit_hip_calibrate_fp8(vit_hip_ctx *ctx, const float *d_images, int n);
+int vit_hip_fp8_scales(const vit_hip_ctx *ctx, float *out, int capacity);
 
 /* Host-pointer forward: gathers the n separately allocated images into pinned
  * staging, runs them in chunks of <= max_batch, and returns when all outputs

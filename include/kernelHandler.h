@@ -150,6 +150,25 @@ int vh_launch_linear_bf16(vh_stream_t s, void *output, int output_bf16, const vo
 int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *output, int n_images,
                              int tokens, int embed_dim, int num_heads);
 
+/* ---- fp8 (OCP e4m3) operand variants (BASELINE config 5) ----
+ * No reference counterpart.  Values are stored as x / scale rounded to e4m3 (saturating at
+ * +-448); a GEMM rescales its raw sum by col_scale[n] = input_scale * weight_row_scale[n]
+ * before adding the bias.  `*_multiplier` arguments are 1 / scale of the tensor written. */
+int vh_launch_convert_fp8(vh_stream_t s, const float *input, void *output, size_t count, float multiplier);
+int vh_launch_quantize_rows_fp8(vh_stream_t s, const float *weight, void *weight_fp8, float *row_scale,
+                                int rows, int cols);                /* row_scale[r] = max|row| / 448 */
+int vh_launch_absmax(vh_stream_t s, const float *input, size_t count, float *amax); /* atomic max into *amax */
+int vh_launch_scale_vector(vh_stream_t s, float *output, const float *input, float multiplier, int count);
+int vh_launch_layer_norm_fp8(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                             void *output, float out_multiplier, int rows, int embed_dim,
+                             long in_row_stride, long out_row_stride, double eps);
+/* output (fp32 when output_kind == 0, e4m3 scaled by out_multiplier when 2) =
+ *   (input_fp8 . weight_fp8^T) * col_scale + bias [+GELU | +residual] */
+int vh_launch_linear_fp8(vh_stream_t s, void *output, int output_kind, const void *weight,
+                         const void *input, const float *bias, const float *col_scale,
+                         float out_multiplier, int rowA, int colA, int colB, int doGelu,
+                         const float *residual);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,3 +184,17 @@ def test_shard_range_covers_batch_exactly_once(pkg):
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= (total + world - 1) // world
+
+
+def test_fp8_reference_round_trips_every_code():
+    """tests/fp8_ref.py (the numpy statement of OCP e4m3 the GPU casts are checked against):
+    every finite code survives dequantise -> quantise, ties go to the even code, overflow
+    saturates at 448."""
+    import fp8_ref
+    codes = np.array([c for c in range(256) if (c & 0x7f) != 0x7f], dtype=np.uint8)
+    vals = fp8_ref.dequantize(codes)
+    back = fp8_ref.quantize(vals)
+    keep = codes != 0x80                                   # -0.0 quantises to +0 or -0: both fine
+    assert np.array_equal(back[keep] & 0x7f, codes[keep] & 0x7f) and np.array_equal(back[keep] >> 7, codes[keep] >> 7)
+    assert fp8_ref.dequantize(fp8_ref.quantize(np.array([1e9, -1e9, 448.0, 464.0], np.float32))).tolist() == [448.0, -448.0, 448.0, 448.0]
+    assert fp8_ref.quantize(np.array([1.0625, 1.1875, 2.0 ** -10], np.float32)).tolist() == [56, 58, 0]

@@ -52,6 +52,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { A_ROWS = 0, A_PATCH = 1 };
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+enum { K_F32 = 0, K_BF16 = 1, K_FP8 = 2 };   /* element kind of GEMM operands / output */
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -77,6 +78,8 @@ struct Tile {
 struct GemmParams {
     const void *A, *W;        /* operands: fp32 or bf16, row-major [M][K] and [N][K] */
     const float *bias, *R, *pos;
+    const float *col_scale;   /* fp8 operands: a_scale * w_scale[n], multiplies the raw sum */
+    float out_scale;          /* fp8 output: multiplier applied before the cast (1 / scale of the next input) */
     void *C;                  /* output: fp32 or bf16 */
     int M, N, K;
     int mtiles, ntiles;
@@ -433,15 +436,16 @@ struct Staging {
  * row: lane l holds out[m = i*16 + (l & 15)][n = j*16 + 4*(l >> 4) + r], r = 0..3, and the
  * bias, residual, position-embedding reads and the store are one 16-byte access each.
  * Operand fragment: lane l holds k = 8*(l >> 4) .. +7 of row (l & 15), natural k order. */
-template <class T, int AMODE, int EPI, bool BF16IN, bool BF16OUT>
+template <class T, int AMODE, int EPI, int INK, int OUTK>
 __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel(const GemmParams p)
 {
     constexpr int BM = T::BM, BN = T::BN;
     constexpr int IT = BM / T::WM / 16, JT = BN / T::WN / 16;   /* 16x16 blocks per wave */
     constexpr int IC = IT < 4 ? IT : 4;                          /* A fragments split at a time */
-    constexpr int ES = BF16IN ? 2 : 4;
+    constexpr bool BF16IN = INK == K_BF16, FP8IN = INK == K_FP8;
+    constexpr int ES = FP8IN ? 1 : BF16IN ? 2 : 4;
     constexpr int KE = 128 / ES;
-    static_assert(!(BF16IN && AMODE == A_PATCH), "im2row loader is fp32 only");
+    static_assert(!(INK != K_F32 && AMODE == A_PATCH), "im2row loader is fp32 only");
     static_assert(IT % IC == 0, "row blocks per wave");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -459,7 +463,9 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     f32x4 acc[IT][JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 16 * JT + j * 16 + 4 * q);
+        /* fp8 operands carry scales: the sum is rescaled before the bias is added (epilogue) */
+        const f32x4 bv = FP8IN ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
+                               : *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 16 * JT + j * 16 + 4 * q);
 #pragma unroll
         for (int i = 0; i < IT; ++i)
             acc[i][j] = bv;
@@ -473,7 +479,29 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
 
     auto compute = [&](int stage) {
         const float *ab = a_lane + stage * T::STAGE_F, *wb = w_lane + stage * T::STAGE_F;
-        if constexpr (BF16IN) {
+        if constexpr (FP8IN) {
+            /* 128 fp8 per LDS row = four 32-deep groups.  One ds_read_b128 (16 bytes) per lane
+             * feeds two MFMAs: lane group q contracts k = 64h + 16q + 8m .. +7 in MFMA (h, m),
+             * the same permutation for both operands. */
+            typedef long i64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int ko = 4 * ((4 * hh + q) ^ swz);
+                i64x2 w[JT];
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+                    w[j] = __builtin_bit_cast(i64x2, *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + ko));
+#pragma unroll
+                for (int i = 0; i < IT; ++i) {
+                    const i64x2 a = __builtin_bit_cast(i64x2, *reinterpret_cast<const f32x4 *>(ab + i * 16 * BK + ko));
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int j = 0; j < JT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w[j][m], a[m], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else if constexpr (BF16IN) {
             /* 64 bf16 per LDS row = two 32-deep groups; one ds_read_b128 per fragment */
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -549,6 +577,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
         for (int j = 0; j < JT; ++j) {
             const int col = n0 + wn * 16 * JT + j * 16 + 4 * q;
             f32x4 v = acc[i][j];
+            if (FP8IN) /* undo the operand scales (per tensor for A, per output column for W), then the bias */
+                v = v * *reinterpret_cast<const f32x4 *>(p.col_scale + col) + *reinterpret_cast<const f32x4 *>(p.bias + col);
             if (EPI == EPI_GELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -558,7 +588,10 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
                 v = *reinterpret_cast<const f32x4 *>(p.R + orow * p.N + col) + v;
             if (EPI == EPI_PATCH)
                 v = v + *reinterpret_cast<const f32x4 *>(posrow + col);
-            if (BF16OUT) {
+            if (OUTK == K_FP8) {
+                *reinterpret_cast<unsigned *>(static_cast<unsigned char *>(p.C) + orow * p.N + col) =
+                    pack_fp8x4(v * p.out_scale);
+            } else if (OUTK == K_BF16) {
                 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                 *reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(p.C) + orow * p.N + col) = o;
@@ -569,18 +602,18 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     }
 }
 
-template <class T, int AMODE, int EPI, bool BF16IN, bool BF16OUT>
+template <class T, int AMODE, int EPI, int INK, int OUTK>
 int launch_mf16(hipStream_t st, GemmParams p)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, BF16IN, BF16OUT>,
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS));
         attr_set = true;
     }
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = p.N / T::BN;
-    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, BF16IN, BF16OUT>), dim3(p.mtiles * p.ntiles),
+    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK>), dim3(p.mtiles * p.ntiles),
                        dim3(T::NT), T::LDS, st, p);
     VH_LAUNCH_CHECK("gemm_mf16_kernel");
     return 0;
@@ -679,9 +712,9 @@ int launch(hipStream_t st, const GemmParams &p, int default_cfg)
             c = 1;
         if (mfma_shape16() && aligned16(p)) {
             switch (c) {
-            case 1: return launch_mf16<Tile1, AMODE, EPI, false, false>(st, p);
-            case 7: return launch_mf16<Tile7, AMODE, EPI, false, false>(st, p);
-            default: return launch_mf16<Tile3, AMODE, EPI, false, false>(st, p);
+            case 1: return launch_mf16<Tile1, AMODE, EPI, K_F32, K_F32>(st, p);
+            case 7: return launch_mf16<Tile7, AMODE, EPI, K_F32, K_F32>(st, p);
+            default: return launch_mf16<Tile3, AMODE, EPI, K_F32, K_F32>(st, p);
             }
         }
         switch (c) {
@@ -751,11 +784,11 @@ int launch_bf16(hipStream_t st, const GemmParams &p)
         cfg = 0;
     if (mfma_shape16() && aligned16(p)) {
         switch (cfg) {
-        case 0: return launch_mf16<Tile0, A_ROWS, EPI, true, BF16OUT>(st, p);
-        case 1: return launch_mf16<Tile1, A_ROWS, EPI, true, BF16OUT>(st, p);
-        case 3: return launch_mf16<Tile3, A_ROWS, EPI, true, BF16OUT>(st, p);
-        case 7: return launch_mf16<Tile7, A_ROWS, EPI, true, BF16OUT>(st, p);
-        default: return launch_mf16<Tile4, A_ROWS, EPI, true, BF16OUT>(st, p);
+        case 0: return launch_mf16<Tile0, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
+        case 1: return launch_mf16<Tile1, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
+        case 3: return launch_mf16<Tile3, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
+        case 7: return launch_mf16<Tile7, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
+        default: return launch_mf16<Tile4, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
         }
     }
     switch (cfg) {
@@ -782,6 +815,170 @@ __global__ void convert_bf16_kernel(const float *__restrict__ in, __bf16 *__rest
 }
 
 } // namespace
+
+namespace {
+
+/* fp8 (OCP e4m3) operands, fp32 accumulate.  Half the operand bytes of bf16 at the same MFMA
+ * rate (non-scaled v_mfma_f32_16x16x32_fp8_fp8); tile choice as for bf16. */
+template <int EPI, int OUTK>
+int launch_fp8(hipStream_t st, const GemmParams &p)
+{
+    int cfg = cfg_override();
+    if (cfg < 0)
+        cfg = (p.N % 256 == 0 && p.M >= 4096) ? 4 : 0;
+    if ((cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7) && p.N % 256 != 0)
+        cfg = 0;
+    switch (cfg) {
+    case 0: return launch_mf16<Tile0, A_ROWS, EPI, K_FP8, OUTK>(st, p);
+    case 1: return launch_mf16<Tile1, A_ROWS, EPI, K_FP8, OUTK>(st, p);
+    case 3: return launch_mf16<Tile3, A_ROWS, EPI, K_FP8, OUTK>(st, p);
+    default: return launch_mf16<Tile4, A_ROWS, EPI, K_FP8, OUTK>(st, p);
+    }
+}
+
+__global__ void convert_fp8_kernel(const float *__restrict__ in, unsigned char *__restrict__ out, size_t n, float mult)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + i);
+        *reinterpret_cast<unsigned *>(out + i) = pack_fp8x4(v * mult);
+    } else {
+        for (size_t k = i; k < n; ++k) {
+            const f32x4 v = {in[k] * mult, 0.0f, 0.0f, 0.0f};
+            out[k] = (unsigned char)(pack_fp8x4(v) & 0xff);
+        }
+    }
+}
+
+__device__ __forceinline__ float block_max_256(float v, float *red)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmaxf(v, __shfl_xor(v, m));
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return v;
+}
+
+/* One block per weight row: scale = max|w| / 448, w8 = fp8(w / scale). */
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const float *__restrict__ w, unsigned char *__restrict__ w8,
+                                                                float *__restrict__ row_scale, int K)
+{
+    __shared__ float red[4];
+    const float *src = w + (size_t)blockIdx.x * K;
+    float mx = 0.0f;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + k);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    mx = block_max_256(mx, red);
+    const float scale = mx > 0.0f ? mx / VH_FP8_MAX : 1.0f;
+    const float inv = 1.0f / scale;
+    if (threadIdx.x == 0)
+        row_scale[blockIdx.x] = scale;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + k);
+        *reinterpret_cast<unsigned *>(w8 + (size_t)blockIdx.x * K + k) = pack_fp8x4(v * inv);
+    }
+}
+
+/* max |x| over a tensor into *amax (non-negative floats order like their bit patterns). */
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ in, size_t n, float *__restrict__ amax)
+{
+    __shared__ float red[4];
+    float mx = 0.0f;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += (size_t)gridDim.x * 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + i);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+        mx = fmaxf(mx, fabsf(in[n - 1 - threadIdx.x]));
+    mx = block_max_256(mx, red);
+    if (threadIdx.x == 0 && mx == mx) /* NaNs are not a maximum */
+        atomicMax(reinterpret_cast<unsigned *>(amax), __builtin_bit_cast(unsigned, mx));
+}
+
+__global__ void scale_vector_kernel(float *__restrict__ out, const float *__restrict__ in, float mult, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = in[i] * mult;
+}
+
+} // namespace
+
+extern "C" int vh_launch_convert_fp8(vh_stream_t s, const float *input, void *output, size_t count, float multiplier)
+{
+    if (!input || !output || count == 0)
+        return vh_fail(1, "vh_launch_convert_fp8: bad argument");
+    const size_t threads = (count + 3) / 4;
+    hipLaunchKernelGGL(convert_fp8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       input, static_cast<unsigned char *>(output), count, multiplier);
+    VH_LAUNCH_CHECK("convert_fp8_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_quantize_rows_fp8(vh_stream_t s, const float *weight, void *weight_fp8, float *row_scale,
+                                           int rows, int cols)
+{
+    if (!weight || !weight_fp8 || !row_scale || rows <= 0 || cols <= 0 || cols % 4 != 0)
+        return vh_fail(1, "vh_launch_quantize_rows_fp8: bad argument (cols must be a multiple of 4)");
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(rows), dim3(256), 0, (hipStream_t)s, weight,
+                       static_cast<unsigned char *>(weight_fp8), row_scale, cols);
+    VH_LAUNCH_CHECK("quantize_rows_fp8_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_absmax(vh_stream_t s, const float *input, size_t count, float *amax)
+{
+    if (!input || !amax || count == 0)
+        return vh_fail(1, "vh_launch_absmax: bad argument");
+    size_t blocks = (count / 4 + 255) / 256;
+    if (blocks > 2048)
+        blocks = 2048;
+    if (blocks == 0)
+        blocks = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, input, count, amax);
+    VH_LAUNCH_CHECK("absmax_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_scale_vector(vh_stream_t s, float *output, const float *input, float multiplier, int count)
+{
+    if (!output || !input || count <= 0)
+        return vh_fail(1, "vh_launch_scale_vector: bad argument");
+    hipLaunchKernelGGL(scale_vector_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)s, output, input,
+                       multiplier, count);
+    VH_LAUNCH_CHECK("scale_vector_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_linear_fp8(vh_stream_t s, void *output, int output_kind, const void *weight,
+                                    const void *input, const float *bias, const float *col_scale, float out_multiplier,
+                                    int rowA, int colA, int colB, int doGelu, const float *residual)
+{
+    if (!output || !weight || !input || !bias || !col_scale)
+        return vh_fail(1, "vh_launch_linear_fp8: null pointer argument");
+    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % 128 != 0 || colB % 128 != 0)
+        return vh_fail(1, "vh_launch_linear_fp8: needs colA %% 128 == 0 and colB %% 128 == 0 (%d,%d,%d)", rowA, colA, colB);
+    if ((output_kind != 0 && output_kind != 2) || (doGelu && residual) || (residual && output_kind != 0))
+        return vh_fail(1, "vh_launch_linear_fp8: unsupported output kind / epilogue combination");
+    GemmParams p = {};
+    p.A = input; p.W = weight; p.bias = bias; p.R = residual; p.C = output;
+    p.col_scale = col_scale; p.out_scale = out_multiplier;
+    p.M = rowA; p.N = colB; p.K = colA;
+    if ((((uintptr_t)output | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)col_scale) & 15) != 0)
+        return vh_fail(1, "vh_launch_linear_fp8: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)s;
+    if (doGelu)
+        return output_kind == 2 ? launch_fp8<EPI_GELU, K_FP8>(st, p) : launch_fp8<EPI_GELU, K_F32>(st, p);
+    if (residual)
+        return launch_fp8<EPI_RESID, K_F32>(st, p);
+    return output_kind == 2 ? launch_fp8<EPI_NONE, K_FP8>(st, p) : launch_fp8<EPI_NONE, K_F32>(st, p);
+}
 
 extern "C" int vh_launch_convert_bf16(vh_stream_t s, const float *input, void *output, size_t count)
 {

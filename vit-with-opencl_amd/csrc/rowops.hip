@@ -35,12 +35,13 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 /* NV = 16-byte chunks per lane; handles embed_dim <= 256*NV, embed_dim % 4 == 0. */
-template <int NV, bool OUTBF16>
+template <int NV, int OUTK> /* OUTK: 0 fp32, 1 bf16, 2 fp8 (scaled by out_mult) */
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta,
                                                         void *__restrict__ out, int rows, int E,
-                                                        long in_stride, long out_stride, double eps)
+                                                        long in_stride, long out_stride, double eps,
+                                                        float out_mult)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(out) + (size_t)row * out_stride);
     bf16x4 *dst16 = reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(out) + (size_t)row * out_stride);
+    unsigned *dst8 = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(out) + (size_t)row * out_stride);
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
         const int idx = c * 64 + lane;
@@ -82,7 +84,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 y[e] = (x[c][e] - mean) * inv_std * g[e] + bb[e];
-            if (OUTBF16) { /* the only consumer is a bf16-operand GEMM: round once, here */
+            if (OUTK == 2) { /* the only consumer is an fp8-operand GEMM: scale and round once, here */
+                dst8[idx] = pack_fp8x4(y * out_mult);
+            } else if (OUTK == 1) { /* the only consumer is a bf16-operand GEMM: round once, here */
                 bf16x4 y16 = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
                 dst16[idx] = y16;
             } else {
@@ -140,8 +144,8 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_kernel(const float *__rest
 } // namespace
 
 static int launch_layer_norm(vh_stream_t s, const float *input, const float *weight, const float *bias,
-                             void *output, int out_bf16, int rows, int embed_dim, long in_row_stride,
-                             long out_row_stride, double eps)
+                             void *output, int out_kind, float out_mult, int rows, int embed_dim,
+                             long in_row_stride, long out_row_stride, double eps)
 {
     if (!input || !weight || !bias || !output)
         return vh_fail(1, "vh_launch_layer_norm: null pointer argument");
@@ -153,20 +157,24 @@ static int launch_layer_norm(vh_stream_t s, const float *input, const float *wei
     hipStream_t st = (hipStream_t)s;
     const dim3 grid((rows + 3) / 4), block(256);
     const int nv = (embed_dim / 4 + 63) / 64;
+#define VH_LN_K(NV, OUTK)                                                                          \
+    hipLaunchKernelGGL((layernorm_kernel<NV, OUTK>), grid, block, 0, st, input, weight, bias, output, \
+                       rows, embed_dim, in_row_stride, out_row_stride, eps, out_mult)
 #define VH_LN(NV)                                                                                   \
     do {                                                                                            \
-        if (out_bf16)                                                                               \
-            hipLaunchKernelGGL((layernorm_kernel<NV, true>), grid, block, 0, st, input, weight, bias, \
-                               output, rows, embed_dim, in_row_stride, out_row_stride, eps);         \
+        if (out_kind == 2)                                                                          \
+            VH_LN_K(NV, 2);                                                                         \
+        else if (out_kind == 1)                                                                     \
+            VH_LN_K(NV, 1);                                                                         \
         else                                                                                        \
-            hipLaunchKernelGGL((layernorm_kernel<NV, false>), grid, block, 0, st, input, weight, bias, \
-                               output, rows, embed_dim, in_row_stride, out_row_stride, eps);         \
+            VH_LN_K(NV, 0);                                                                         \
     } while (0)
     if (nv <= 3) VH_LN(3);
     else if (nv <= 4) VH_LN(4);
     else if (nv <= 5) VH_LN(5);
     else VH_LN(8);
 #undef VH_LN
+#undef VH_LN_K
     VH_LAUNCH_CHECK("layernorm_kernel");
     return 0;
 }
@@ -175,7 +183,7 @@ extern "C" int vh_launch_layer_norm(vh_stream_t s, const float *input, const flo
                                     const float *bias, float *output, int rows, int embed_dim,
                                     long in_row_stride, long out_row_stride, double eps)
 {
-    return launch_layer_norm(s, input, weight, bias, output, 0, rows, embed_dim, in_row_stride,
+    return launch_layer_norm(s, input, weight, bias, output, 0, 1.0f, rows, embed_dim, in_row_stride,
                              out_row_stride, eps);
 }
 
@@ -183,7 +191,15 @@ extern "C" int vh_launch_layer_norm_bf16(vh_stream_t s, const float *input, cons
                                          const float *bias, void *output, int rows, int embed_dim,
                                          long in_row_stride, long out_row_stride, double eps)
 {
-    return launch_layer_norm(s, input, weight, bias, output, 1, rows, embed_dim, in_row_stride,
+    return launch_layer_norm(s, input, weight, bias, output, 1, 1.0f, rows, embed_dim, in_row_stride,
+                             out_row_stride, eps);
+}
+
+extern "C" int vh_launch_layer_norm_fp8(vh_stream_t s, const float *input, const float *weight,
+                                        const float *bias, void *output, float out_multiplier, int rows,
+                                        int embed_dim, long in_row_stride, long out_row_stride, double eps)
+{
+    return launch_layer_norm(s, input, weight, bias, output, 2, out_multiplier, rows, embed_dim, in_row_stride,
                              out_row_stride, eps);
 }
 

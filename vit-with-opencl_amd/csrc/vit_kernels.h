@@ -11,6 +11,18 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+/* Four fp32 values -> four OCP e4m3 bytes (gfx950's fp8), round to nearest even, saturating
+ * at the format's largest finite value instead of overflowing to NaN. */
+#define VH_FP8_MAX 448.0f
+__device__ __forceinline__ unsigned pack_fp8x4(f32x4 v)
+{
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[0], -VH_FP8_MAX, VH_FP8_MAX),
+                                            __builtin_amdgcn_fmed3f(v[1], -VH_FP8_MAX, VH_FP8_MAX), 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[2], -VH_FP8_MAX, VH_FP8_MAX),
+                                        __builtin_amdgcn_fmed3f(v[3], -VH_FP8_MAX, VH_FP8_MAX), r, true);
+    return (unsigned)r;
+}
+
 /* Records `msg` as the calling thread's last error and returns `code`. */
 int vh_fail(int code, const char *fmt, ...);
 /* Converts a hipError_t into the launcher return convention, recording text. */

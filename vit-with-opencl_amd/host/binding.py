@@ -36,6 +36,8 @@ EXPORTS = [
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_create_ex", "vit_hip_precision",
     "vh_launch_convert_bf16", "vh_launch_layer_norm_bf16", "vh_launch_linear_bf16", "vh_launch_attention_bf16",
     "vh_patch_embed_workspace", "vh_launch_patch_embed_ws",
+    "vh_launch_convert_fp8", "vh_launch_quantize_rows_fp8", "vh_launch_absmax", "vh_launch_scale_vector",
+    "vh_launch_layer_norm_fp8", "vh_launch_linear_fp8", "vit_hip_calibrate_fp8", "vit_hip_fp8_scales",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
     "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
 ]
@@ -142,6 +144,15 @@ def lib() -> C.CDLL:
     L.vh_launch_layer_norm_bf16.argtypes = [voidp] + [voidp] * 4 + [i, i, C.c_long, C.c_long, C.c_double]
     L.vh_launch_linear_bf16.argtypes = [voidp, voidp, i, voidp, voidp, voidp, i, i, i, i, voidp]
     L.vh_launch_attention_bf16.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    f = C.c_float
+    L.vh_launch_convert_fp8.argtypes = [voidp, voidp, voidp, sz, f]
+    L.vh_launch_quantize_rows_fp8.argtypes = [voidp, voidp, voidp, voidp, i, i]
+    L.vh_launch_absmax.argtypes = [voidp, voidp, sz, voidp]
+    L.vh_launch_scale_vector.argtypes = [voidp, voidp, voidp, f, i]
+    L.vh_launch_layer_norm_fp8.argtypes = [voidp] + [voidp] * 4 + [f, i, i, C.c_long, C.c_long, C.c_double]
+    L.vh_launch_linear_fp8.argtypes = [voidp, voidp, i, voidp, voidp, voidp, voidp, f, i, i, i, i, voidp]
+    L.vit_hip_calibrate_fp8.argtypes = [voidp, voidp, i]
+    L.vit_hip_fp8_scales.argtypes = [voidp, f32p, i]
     L.vit_hip_destroy.argtypes = [voidp]
     L.vit_hip_destroy.restype = None
     L.vit_hip_forward.argtypes = [voidp, C.POINTER(ImageData), i, f32p, C.POINTER(f32p)]
@@ -272,7 +283,7 @@ class ViTHip:
         self.ctx = voidp()
         self.precision = precision
         rc = self.L.vit_hip_create_ex(C.byref(self.ctx), C.byref(cfg), networks(weights), len(weights),
-                                      device, max_batch, {"f32": 0, "bf16": 1}[precision])
+                                      device, max_batch, {"f32": 0, "bf16": 1, "fp8": 2}[precision])
         check(rc, "vit_hip_create_ex")
         self.max_batch = max_batch
         self.tokens = tokens(cfg)
@@ -295,6 +306,21 @@ class ViTHip:
         """Device-resident path; pointers are ints / c_void_p / DeviceBuffer.ptr."""
         check(self.L.vit_hip_forward_device(self.ctx, d_images, n, d_logits, d_probs, stream),
               "vit_hip_forward_device")
+
+    def calibrate_fp8(self, images: np.ndarray) -> np.ndarray:
+        """FP8_GEMM contexts: record the GEMM-input ranges over `images` ([n][C][H][W], host);
+        returns the scales [depth][4] (LN1 out, attention out, LN2 out, MLP hidden)."""
+        d = DeviceBuffer.from_numpy(np.ascontiguousarray(images, dtype=np.float32))
+        try:
+            return self.calibrate_fp8_device(d.ptr, images.shape[0])
+        finally:
+            d.free()
+
+    def calibrate_fp8_device(self, d_images, n: int) -> np.ndarray:
+        check(self.L.vit_hip_calibrate_fp8(self.ctx, d_images, n), "vit_hip_calibrate_fp8")
+        out = np.zeros(4 * self.cfg.depth, dtype=np.float32)
+        got = self.L.vit_hip_fp8_scales(self.ctx, fptr(out), out.size)
+        return out[:got].reshape(-1, 4)
 
     def sync(self):
         check(self.L.vh_stream_sync(self.stream), "vh_stream_sync")
