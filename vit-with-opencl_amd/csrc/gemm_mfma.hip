@@ -1,6 +1,5 @@
 /*
- * gemm_mfma.hip -- the dense projections of the ViT forward pass on the gfx950
- * matrix cores: exact fp32 (the parity path) and bf16 operands with fp32 accumulation.
+ * gemm_mfma.hip -- the dense projections of the ViT forward pass on the gfx950 matrix cores.
  *
  *   C[M][N] = A[M][K] . W[N][K]^T  (+ bias, + GELU | + residual | patch epilogue)
  *
@@ -9,34 +8,37 @@
  * (layer_norm.cl:55-65) and -- through the im2row A-loader and the token
  * epilogue -- `conv2d_kernel` + `postprocess` (conv2d.cl:1-80).
  *
- * Design (MI355X / CDNA4):
- *  - v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit a k-ordered
- *    fmaf chain, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak.  There is no
- *    TF32-like shortcut on gfx950, so this is the fp32 roofline.
- *  - Block tiles of BM x BN x 32 (template: 128x128 ... 256x256) cut into WM x WN
- *    waves, each wave IT x JT MFMA tiles of 32x32.  Both operands are K-contiguous
- *    ("NT" GEMM), so A and W use the same LDS image: 128-byte rows whose 16-byte
- *    chunks are XOR-swizzled (chunk c of row r at c ^ ((r >> 1) & 7)), which makes
- *    every ds_read_b128 fragment read conflict-free (the 16 rows of a lane group
- *    hit 16 distinct 16-B slots of the 256-B bank row).
- *  - One ds_read_b128 per 32-row fragment yields four k-pairs: lane l holds
- *    k = 8*kk + 4*(l>>5) + e in register e, and MFMA step e contracts the
- *    pair {e, 4+e}; A and W use the same permutation, so only the summation
- *    order inside an 8-wide k group differs from the scalar loop.
- *  - K-tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA): no staging
- *    VGPRs, no ds_write instructions.  An LDS-DMA wave-instruction writes 64 x 16 B
- *    linearly (wave-uniform base + lane*16), so rows cannot be padded; the swizzle
- *    is applied to the per-lane SOURCE address and, identically, to the reads.
- *    Two LDS stages: step t issues the DMA of K-tile t+1 into the stage read in
- *    step t-1 right after the barrier, computes K-tile t, and __syncthreads()
- *    (vmcnt(0) + barrier) publishes K-tile t+1 -- a load has a whole step of MFMAs
- *    to land.
+ * Arithmetic (operands -> matrix instruction), all with fp32 accumulation:
+ *   fp32, default   exact 3-way bf16 split of both operands, six v_mfma_f32_16x16x32_bf16 per
+ *                   product block (SPLIT3 below): fp32-level results at 2.67x the fp32 MFMA peak
+ *   fp32, native    v_mfma_f32_32x32x2_f32 (VIT_HIP_GEMM_FP32=native; also the ragged-N classifier)
+ *   bf16            v_mfma_f32_16x16x32_bf16           (BASELINE config 3, opt-in)
+ *   fp8 (e4m3)      v_mfma_f32_16x16x32_fp8_fp8 + per-column rescale (BASELINE config 5, opt-in)
+ * Two kernel templates share one staging scheme: gemm_mf16_kernel (the 16x16x32 shapes) and
+ * gemm_f32_kernel (native fp32, ragged N, and the 32x32x16 form of SPLIT3 behind
+ * VIT_HIP_GEMM_MFMA=32 -- under load the chip holds a higher clock on 16x16x32).
+ *
+ * Staging (MI355X / CDNA4):
+ *  - Block tiles of BM x BN (template: 128x128 ... 256x256) x one 128-byte K step, cut into
+ *    WM x WN waves.  Both operands are K-contiguous ("NT" GEMM), so A and W use the same LDS
+ *    image: 128-byte rows whose 16-byte chunks are XOR-swizzled (chunk c of row r at
+ *    c ^ ((r >> 1) & 7)), which makes every ds_read_b128 fragment read conflict-free (the 16
+ *    rows of a lane group hit 16 distinct 16-B slots of the 256-B bank row).
+ *  - K-tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA): no staging VGPRs, no
+ *    ds_write instructions.  An LDS-DMA wave-instruction writes 64 x 16 B linearly
+ *    (wave-uniform base + lane*16), so rows cannot be padded; the swizzle is applied to the
+ *    per-lane SOURCE address and, identically, to the reads.  Two LDS stages: step t issues the
+ *    DMA of K-tile t+1 into the stage read in step t-1 right after the barrier, computes
+ *    K-tile t, and __syncthreads() (vmcnt(0) + barrier) publishes K-tile t+1 -- a load has a
+ *    whole step of MFMAs to land.
+ *  - The contraction order inside a K step is permuted to suit the fragment reads (the same
+ *    permutation for A and W), so only the summation order differs from the scalar loop.
  *  - The accumulator starts at the bias, like the scalar loop it replaces
- *    (`sum = bias[o]`, ViT_seq.c:301), and the residual is added to the
- *    finished sum (ViT_seq.c:350,362).
- *  - blockIdx -> tile map is XCD-aware: each of the 8 XCDs walks a contiguous
- *    range of tiles, N fastest, so the blocks resident on one XCD share A row
- *    panels and W column panels in that XCD's private 4 MiB L2.
+ *    (`sum = bias[o]`, ViT_seq.c:301), and the residual is added to the finished sum
+ *    (ViT_seq.c:350,362).
+ *  - blockIdx -> tile map is XCD-aware: each of the 8 XCDs walks a contiguous range of tiles,
+ *    N fastest, so the blocks resident on one XCD share A row panels and W column panels in
+ *    that XCD's private 4 MiB L2.
  */
 #include "kernelHandler.h"
 #include "vit_kernels.h"
