@@ -54,7 +54,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { A_ROWS = 0, A_PATCH = 1 };
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
-enum { K_F32 = 0, K_BF16 = 1, K_FP8 = 2 };   /* element kind of GEMM operands / output */
+enum { K_F32 = 0, K_BF16 = 1, K_FP8 = 2 };
+#ifndef SGB_M
+#define SGB_M 1   /* scheduled SPLIT3 loop: SGB_M MFMAs, then SGB_V VALU instructions, repeated */
+#define SGB_V 2
+#endif   /* element kind of GEMM operands / output */
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -438,7 +442,7 @@ struct Staging {
  * row: lane l holds out[m = i*16 + (l & 15)][n = j*16 + 4*(l >> 4) + r], r = 0..3, and the
  * bias, residual, position-embedding reads and the store are one 16-byte access each.
  * Operand fragment: lane l holds k = 8*(l >> 4) .. +7 of row (l & 15), natural k order. */
-template <class T, int AMODE, int EPI, int INK, int OUTK>
+template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false>
 __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel(const GemmParams p)
 {
     constexpr int BM = T::BM, BN = T::BN;
@@ -519,6 +523,60 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
                     for (int j = 0; j < JT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a, acc[i][j], 0, 0, 0);
                 }
+            }
+        } else if constexpr (SCHED) {
+            /* Fragment-grained pipeline inside the K step: group i issues the LDS reads of A
+             * fragment i+2, splits fragment i+1 and runs the 6*JT MFMAs of fragment i, the
+             * MFMA / VALU interleave pinned with sched_group_barrier (left alone, the compiler
+             * emits the splits of several fragments, then their MFMAs, and the matrix pipe
+             * idles during the former).  The W splits and the first A split stay exposed
+             * (hiding them too -- a per-W-fragment ramp, or carrying the next step's W across
+             * the barrier -- measured slower). */
+            static_assert(IT >= 2, "pipeline depth");
+            const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
+            bf16x8 w0[JT], w1[JT], w2[JT], c0, c1, c2;
+            f32x4 ra[2][2];
+            ra[0][0] = *reinterpret_cast<const f32x4 *>(ab + k0);
+            ra[0][1] = *reinterpret_cast<const f32x4 *>(ab + k1);
+            ra[1][0] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k0);
+            ra[1][1] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k1);
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+                split8(*reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k0),
+                       *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k1), w0[j], w1[j], w2[j]);
+            split8(ra[0][0], ra[0][1], c0, c1, c2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                bf16x8 n0, n1, n2;
+                if (i + 1 < IT)
+                    split8(ra[(i + 1) & 1][0], ra[(i + 1) & 1][1], n0, n1, n2);
+                if (i + 2 < IT) {
+                    ra[i & 1][0] = *reinterpret_cast<const f32x4 *>(ab + (i + 2) * 16 * BK + k0);
+                    ra[i & 1][1] = *reinterpret_cast<const f32x4 *>(ab + (i + 2) * 16 * BK + k1);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) { /* per accumulator: smallest terms first */
+                        const bf16x8 wp = (t == 0 || t == 3 || t == 5) ? w0[j] : (t == 1) ? w2[j] : w1[j];
+                        const bf16x8 ap = (t == 0) ? c2 : (t == 2 || t == 3) ? c1 : c0;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp, ap, acc[i][j], 0, 0, 0);
+                    }
+                if (i + 1 < IT) {
+                    if (i + 2 < IT)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int r = 0; r < (6 * JT - 2) / SGB_M; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, SGB_M, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, SGB_V, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6 * JT - (6 * JT - 2) / SGB_M * SGB_M, 0);
+                    c0 = n0;
+                    c1 = n1;
+                    c2 = n2;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
@@ -604,18 +662,18 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     }
 }
 
-template <class T, int AMODE, int EPI, int INK, int OUTK>
+template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false>
 int launch_mf16(hipStream_t st, GemmParams p)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK>,
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS));
         attr_set = true;
     }
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = p.N / T::BN;
-    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK>), dim3(p.mtiles * p.ntiles),
+    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED>), dim3(p.mtiles * p.ntiles),
                        dim3(T::NT), T::LDS, st, p);
     VH_LAUNCH_CHECK("gemm_mf16_kernel");
     return 0;
@@ -693,6 +751,16 @@ bool mfma_shape16()
     return v == 1;
 }
 
+bool sched_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *env = getenv("VIT_HIP_GEMM_SCHED");   /* "0": the compiler's own instruction order */
+        v = (env && env[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 bool aligned16(const GemmParams &p)
 {
     return (((uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.R | (uintptr_t)p.pos) & 15) == 0;
@@ -712,6 +780,12 @@ int launch(hipStream_t st, const GemmParams &p, int default_cfg)
             c = (p.N % 256 == 0 && p.M >= 4096 && !(EPI == EPI_RESID && p.K < 2048)) ? 3 : 1;
         if ((c == 3 || c == 4 || c == 7) && p.N % 256 != 0)
             c = 1;
+        if (mfma_shape16() && aligned16(p) && sched_variant()) {
+            switch (c) {
+            case 1: return launch_mf16<Tile1, AMODE, EPI, K_F32, K_F32, true>(st, p);
+            default: return launch_mf16<Tile3, AMODE, EPI, K_F32, K_F32, true>(st, p);
+            }
+        }
         if (mfma_shape16() && aligned16(p)) {
             switch (c) {
             case 1: return launch_mf16<Tile1, AMODE, EPI, K_F32, K_F32>(st, p);

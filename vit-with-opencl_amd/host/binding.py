@@ -100,7 +100,8 @@ def lib() -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
-    L = C.CDLL(str(LIB_PATH))
+    # VIT_HIP_LIB: a differently built copy of the same library (kernel tuning experiments only)
+    L = C.CDLL(os.environ.get("VIT_HIP_LIB") or str(LIB_PATH))
     i, sz = C.c_int, C.c_size_t
     L.vh_last_error.restype = C.c_char_p
     L.vh_device_name.restype = C.c_char_p
