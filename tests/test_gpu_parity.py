@@ -79,6 +79,38 @@ def test_linear_vs_oracle(pkg, device, oracle, M, K, N, gelu, resid):
     assert np.abs(got - want).max() <= OP_TOL
 
 
+@pytest.mark.parametrize("M,K,N,gelu,resid", [
+    (197, 768, 2304, 0, False), (197, 768, 768, 0, True), (300, 768, 3072, 1, False), (5000, 3072, 768, 0, True),
+    (4300, 768, 3072, 1, False),       # the 256x256-tile path (M >= 4096)
+])
+def test_linear_presplit_weight_planes_matches_fp32_weights(pkg, device, oracle, M, K, N, gelu, resid):
+    """vh_launch_linear_w3 (weights split into three bf16 planes ahead of time) against the oracle
+    and, bit for bit, against vh_launch_linear on the fp32 weights: the same six products per
+    block in the same order, only where the split happens differs."""
+    x = oracle.synth_fill(M * K, 300 + M, 1.0, 0.1).reshape(M, K)
+    w = oracle.synth_fill(N * K, 301 + N, 0.04, 0.0)
+    b = oracle.synth_fill(N, 302, 0.1, 0.0)
+    r = oracle.synth_fill(M * N, 303, 1.0, 0.0).reshape(M, N)
+    d_x, d_w, d_b, d_r = _dev(pkg, x), _dev(pkg, w), _dev(pkg, b), _dev(pkg, r)
+    d_w3 = pkg.DeviceBuffer((3 * N * K + 1) // 2)
+    _launch(pkg, "vh_launch_split3_planes", None, d_w.ptr, d_w3.ptr, N * K)
+    planes = d_w3.to_numpy().view(np.uint16)[:3 * N * K].reshape(3, N * K)
+    parts = (planes.astype(np.uint32) << 16).view(np.float32)
+    assert np.array_equal(parts[0].astype(np.float64) + parts[1] + parts[2], w.astype(np.float64))   # exact split
+    d_o1, d_o2 = pkg.DeviceBuffer(M * N), pkg.DeviceBuffer(M * N)
+    _launch(pkg, "vh_launch_linear_w3", None, d_o1.ptr, d_w3.ptr, d_x.ptr, d_b.ptr, M, K, N, gelu, d_r.ptr if resid else None)
+    _launch(pkg, "vh_launch_linear", None, d_o2.ptr, d_w.ptr, d_x.ptr, d_b.ptr, M, K, N, gelu, d_r.ptr if resid else None)
+    got, ref = d_o1.to_numpy((M, N)), d_o2.to_numpy((M, N))
+    assert np.array_equal(got, ref)
+    if M <= 300:
+        want = oracle.linear(x, w, b, N)
+        if gelu:
+            want = oracle.gelu(want.ravel()).reshape(M, N)
+        if resid:
+            want = r + want
+        assert np.abs(got - want).max() <= OP_TOL
+
+
 def test_linear_rejects_bad_arguments(pkg, device):
     L = pkg.lib()
     d = pkg.DeviceBuffer(1024)

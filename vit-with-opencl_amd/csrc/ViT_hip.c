@@ -50,6 +50,9 @@ struct vit_hip_ctx
     void **w16;         /* per tensor index (NULL where no bf16 copy exists) */
     /* FP8_GEMM: e4m3 copies of the same four matrices with one scale per output row, the
      * calibrated per-tensor scales of the four GEMM inputs of every layer, and their products */
+    /* F32: the same four matrices pre-split into three bf16 planes each (vh_launch_linear_w3) */
+    void *w3_slab;
+    void **w3;          /* per tensor index (NULL: use the fp32 tensor) */
     void *w8_slab;
     void **w8;          /* per tensor index */
     float *wscale_slab; /* per tensor index: [out_features] row scales, then [out_features] a_scale*row scale */
@@ -149,6 +152,9 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
     if (ctx->w16_slab)
         vh_free(ctx->w16_slab);
     free(ctx->w16);
+    if (ctx->w3_slab)
+        vh_free(ctx->w3_slab);
+    free(ctx->w3);
     if (ctx->w8_slab)
         vh_free(ctx->w8_slab);
     if (ctx->wscale_slab)
@@ -227,13 +233,15 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
     ctx->precision = precision;
     ctx->w = (float **)calloc((size_t)n_tensors, sizeof(float *));
     ctx->w16 = (void **)calloc((size_t)n_tensors, sizeof(void *));
+    ctx->w3 = (void **)calloc((size_t)n_tensors, sizeof(void *));
     ctx->w8 = (void **)calloc((size_t)n_tensors, sizeof(void *));
     ctx->wscale = (float **)calloc((size_t)n_tensors, sizeof(float *));
     ctx->colscale = (float **)calloc((size_t)n_tensors, sizeof(float *));
     ctx->act_scale = (float *)calloc((size_t)cfg->depth * 4, sizeof(float));
-    if (!ctx->w || !ctx->w16 || !ctx->w8 || !ctx->wscale || !ctx->colscale || !ctx->act_scale) {
+    if (!ctx->w || !ctx->w16 || !ctx->w3 || !ctx->w8 || !ctx->wscale || !ctx->colscale || !ctx->act_scale) {
         free(ctx->w);
         free(ctx->w16);
+        free(ctx->w3);
         free(ctx->w8);
         free(ctx->wscale);
         free(ctx->colscale);
@@ -273,6 +281,26 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
                 ctx->w16[idx] = (char *)ctx->w16_slab + off16;
                 TRY(vh_launch_convert_bf16(ctx->stream, ctx->w[idx], ctx->w16[idx], networks[idx].size));
                 off16 += align_up(networks[idx].size * 2, 256);
+            }
+    }
+
+    const char *env_w3 = getenv("VIT_HIP_W3");
+    if (precision == VIT_PRECISION_F32 && !(env_w3 && env_w3[0] == '0') && cfg->embed_dim % 128 == 0 &&
+        cfg->mlp_hidden % 128 == 0) {
+        /* the constant GEMM operand split once (exact 3-way bf16 split, 6 bytes per weight) */
+        static const int big[4] = {2, 4, 8, 10};
+        size_t total3 = 0;
+        for (int l = 0; l < cfg->depth; ++l)
+            for (int k = 0; k < 4; ++k)
+                total3 += align_up(networks[4 + 12 * l + big[k]].size * 6, 256);
+        TRY(vh_malloc(&ctx->w3_slab, total3));
+        size_t off3 = 0;
+        for (int l = 0; l < cfg->depth; ++l)
+            for (int k = 0; k < 4; ++k) {
+                const int idx = 4 + 12 * l + big[k];
+                ctx->w3[idx] = (char *)ctx->w3_slab + off3;
+                TRY(vh_launch_split3_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], networks[idx].size));
+                off3 += align_up(networks[idx].size * 6, 256);
             }
     }
 
@@ -394,18 +422,23 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
         if (amax)
             TRY(vh_launch_absmax(s, ctx->y, (size_t)rows * E, amax + 0));
-        OP(VIT_OP_QKV, vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+        void **l3 = ctx->w3 + 4 + 12 * l;   /* pre-split weight planes, when built */
+        OP(VIT_OP_QKV, l3[2] ? vh_launch_linear_w3(s, ctx->qkv, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL)
+                             : vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
         OP(VIT_OP_ATTENTION, vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
         if (amax)
             TRY(vh_launch_absmax(s, ctx->attn, (size_t)rows * E, amax + 1));
-        OP(VIT_OP_OUT_PROJ, vh_launch_linear(s, ctx->x, lw[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+        OP(VIT_OP_OUT_PROJ, l3[4] ? vh_launch_linear_w3(s, ctx->x, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x)
+                                  : vh_launch_linear(s, ctx->x, lw[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
         if (amax)
             TRY(vh_launch_absmax(s, ctx->y, (size_t)rows * E, amax + 2));
-        OP(VIT_OP_FC1, vh_launch_linear(s, ctx->hid, lw[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+        OP(VIT_OP_FC1, l3[8] ? vh_launch_linear_w3(s, ctx->hid, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL)
+                             : vh_launch_linear(s, ctx->hid, lw[8], ctx->y, lw[9], rows, E, F, 1, NULL));
         if (amax)
             TRY(vh_launch_absmax(s, ctx->hid, (size_t)rows * F, amax + 3));
-        OP(VIT_OP_FC2, vh_launch_linear(s, ctx->x, lw[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+        OP(VIT_OP_FC2, l3[10] ? vh_launch_linear_w3(s, ctx->x, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x)
+                              : vh_launch_linear(s, ctx->x, lw[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
     }
 
     /* final LayerNorm on the class-token rows, classifier, softmax (ViT_seq.c:506-515) */

@@ -75,6 +75,10 @@ struct Tile {
     static constexpr int CHW = BN / 8 / NW;          /* 8-row DMA pieces per wave, W */
     static constexpr int STAGE_F = (BM + BN) * BK;   /* floats per LDS stage */
     static constexpr size_t LDS = sizeof(float) * 2 * STAGE_F;
+    /* W as three pre-split bf16 planes (W3): BN rows x 64 B per plane instead of BN x 128 B */
+    static constexpr int STAGE_F3 = (BM + BN + BN / 2) * BK;
+    static constexpr size_t LDS3 = sizeof(float) * 2 * STAGE_F3;
+    static constexpr int CHW3 = 3 * BN / 16 / NW;    /* 16-row DMA pieces of a W plane per wave */
     static constexpr int WG_PER_CU = (2 * LDS <= 160 * 1024) ? 2 : 1;
     static constexpr int MIN_WAVES_PER_SIMD = WG_PER_CU * NW / 4;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "DMA pieces must divide evenly over waves");
@@ -379,9 +383,11 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
 /* Operand staging shared by the 16x16x32 kernel below: per-lane source addresses of the
  * 8-row LDS-DMA pieces (same LDS image as gemm_f32_kernel: 128-byte rows, chunk c of row r
  * at c ^ ((r >> 1) & 7)). */
-template <class T, int AMODE, int ES>
+template <class T, int AMODE, int ES, bool W3 = false>
 struct Staging {
-    const char *a_src[T::CHA], *w_src[T::CHW];
+    static constexpr int NWP = W3 ? T::CHW3 : T::CHW;     /* W pieces per wave */
+    static constexpr int STAGE = W3 ? T::STAGE_F3 : T::STAGE_F;
+    const char *a_src[T::CHA], *w_src[NWP];
     int a_k[T::CHA];
 
     __device__ __forceinline__ void init(const GemmParams &p, int m0, int n0, int wave, int lane)
@@ -403,17 +409,31 @@ struct Staging {
                     (size_t)ow * p.patch);
             }
         }
+        if constexpr (W3) {
+            /* p.W = [3][N][K] bf16 planes.  Piece pc = 16 rows x 64 B of one plane; lane fills
+             * physical 16-byte chunk (lane & 3) of row (lane >> 2) with logical chunk
+             * phys ^ ((row >> 2) & 3) (64-byte rows: the 16 rows of a fragment read then hit
+             * 16 distinct 16-byte slots of the bank row). */
 #pragma unroll
-        for (int i = 0; i < T::CHW; ++i) {
-            const int r = 8 * (wave * T::CHW + i) + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-            w_src[i] = static_cast<const char *>(p.W) + (size_t)(n0 + r) * p.K * ES + 16 * chunk;
+            for (int i = 0; i < NWP; ++i) {
+                const int pc = wave * NWP + i, plane = pc / (T::BN / 16), rb = pc - plane * (T::BN / 16);
+                const int r = 16 * rb + (lane >> 2);
+                const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+                w_src[i] = static_cast<const char *>(p.W) + (((size_t)plane * p.N + n0 + r) * p.K) * 2 + 16 * chunk;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NWP; ++i) {
+                const int r = 8 * (wave * NWP + i) + (lane >> 3);
+                const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+                w_src[i] = static_cast<const char *>(p.W) + (size_t)(n0 + r) * p.K * ES + 16 * chunk;
+            }
         }
     }
 
     __device__ __forceinline__ void dma(const GemmParams &p, float *smem, int stage, int kt, int wave) const
     {
-        float *As = smem + stage * T::STAGE_F, *Ws = As + T::BM * BK;
+        float *As = smem + stage * STAGE, *Ws = As + T::BM * BK;
 #pragma unroll
         for (int i = 0; i < T::CHA; ++i) {
             const char *ap;
@@ -428,9 +448,9 @@ struct Staging {
             __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(As + (wave * T::CHA + i) * 8 * BK), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < T::CHW; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (size_t)kt * 128),
-                                             (lptr_t)(Ws + (wave * T::CHW + i) * 8 * BK), 16, 0, 0);
+        for (int i = 0; i < NWP; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (size_t)kt * (W3 ? 64 : 128)),
+                                             (lptr_t)(Ws + (wave * NWP + i) * 8 * BK), 16, 0, 0);
     }
 };
 
@@ -442,7 +462,7 @@ struct Staging {
  * row: lane l holds out[m = i*16 + (l & 15)][n = j*16 + 4*(l >> 4) + r], r = 0..3, and the
  * bias, residual, position-embedding reads and the store are one 16-byte access each.
  * Operand fragment: lane l holds k = 8*(l >> 4) .. +7 of row (l & 15), natural k order. */
-template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false>
+template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false, bool W3 = false>
 __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel(const GemmParams p)
 {
     constexpr int BM = T::BM, BN = T::BN;
@@ -463,7 +483,9 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / T::WN, wn = wave % T::WN, l15 = lane & 15, q = lane >> 4;
 
-    Staging<T, AMODE, ES> stg;
+    static_assert(!W3 || (SCHED && INK == K_F32), "pre-split weight planes go with the scheduled fp32 loop");
+    constexpr int STG = W3 ? T::STAGE_F3 : T::STAGE_F;   /* floats per LDS stage */
+    Staging<T, AMODE, ES, W3> stg;
     stg.init(p, m0, n0, wave, lane);
 
     f32x4 acc[IT][JT];
@@ -484,7 +506,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
 
 
     auto compute = [&](int stage) {
-        const float *ab = a_lane + stage * T::STAGE_F, *wb = w_lane + stage * T::STAGE_F;
+        const float *ab = a_lane + stage * STG, *wb = w_lane + stage * STG;
         if constexpr (FP8IN) {
             /* 128 fp8 per LDS row = four 32-deep groups.  One ds_read_b128 (16 bytes) per lane
              * feeds two MFMAs: lane group q contracts k = 64h + 16q + 8m .. +7 in MFMA (h, m),
@@ -540,10 +562,21 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             ra[0][1] = *reinterpret_cast<const f32x4 *>(ab + k1);
             ra[1][0] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k0);
             ra[1][1] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k1);
+            if constexpr (W3) {
+                /* weights were split once, at context creation: three bf16 planes of 64-byte rows */
+                const float *w3 = smem + stage * STG + BM * BK + (wn * 16 * JT + l15) * 16 + 4 * (q ^ ((l15 >> 2) & 3));
 #pragma unroll
-            for (int j = 0; j < JT; ++j)
-                split8(*reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k0),
-                       *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k1), w0[j], w1[j], w2[j]);
+                for (int j = 0; j < JT; ++j) {
+                    w0[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + j * 256));
+                    w1[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + BN * 16 + j * 256));
+                    w2[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + 2 * BN * 16 + j * 256));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+                    split8(*reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k0),
+                           *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k1), w0[j], w1[j], w2[j]);
+            }
             split8(ra[0][0], ra[0][1], c0, c1, c2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -566,10 +599,11 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
                 if (i + 1 < IT) {
                     if (i + 2 < IT)
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    constexpr int VPM = JT >= 8 ? 1 : SGB_V;   /* ~44 split instructions over the group's MFMAs */
 #pragma unroll
                     for (int r = 0; r < (6 * JT - 2) / SGB_M; ++r) {
                         __builtin_amdgcn_sched_group_barrier(0x008, SGB_M, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, SGB_V, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 6 * JT - (6 * JT - 2) / SGB_M * SGB_M, 0);
                     c0 = n0;
@@ -662,19 +696,19 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     }
 }
 
-template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false>
+template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false, bool W3 = false>
 int launch_mf16(hipStream_t st, GemmParams p)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS));
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, W3>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W3 ? T::LDS3 : T::LDS)));
         attr_set = true;
     }
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = p.N / T::BN;
-    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED>), dim3(p.mtiles * p.ntiles),
-                       dim3(T::NT), T::LDS, st, p);
+    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, W3>), dim3(p.mtiles * p.ntiles),
+                       dim3(T::NT), W3 ? T::LDS3 : T::LDS, st, p);
     VH_LAUNCH_CHECK("gemm_mf16_kernel");
     return 0;
 }
@@ -783,6 +817,7 @@ int launch(hipStream_t st, const GemmParams &p, int default_cfg)
         if (mfma_shape16() && aligned16(p) && sched_variant()) {
             switch (c) {
             case 1: return launch_mf16<Tile1, AMODE, EPI, K_F32, K_F32, true>(st, p);
+            case 7: return launch_mf16<Tile7, AMODE, EPI, K_F32, K_F32, true>(st, p);
             default: return launch_mf16<Tile3, AMODE, EPI, K_F32, K_F32, true>(st, p);
             }
         }
@@ -985,6 +1020,69 @@ __global__ void scale_vector_kernel(float *__restrict__ out, const float *__rest
 }
 
 } // namespace
+
+namespace {
+
+/* fp32 [n] -> three bf16 planes [3][n]: x = p0 + p1 + p2 exactly (the SPLIT3 parts), done once
+ * for the weights so that the GEMM's inner loop splits only the activations. */
+__global__ void split3_planes_kernel(const float *__restrict__ in, __bf16 *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float x = in[i];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    out[i] = h;
+    out[n + i] = m;
+    out[2 * n + i] = (__bf16)r2;
+}
+
+} // namespace
+
+extern "C" int vh_launch_split3_planes(vh_stream_t s, const float *input, void *planes, size_t count)
+{
+    if (!input || !planes || count == 0)
+        return vh_fail(1, "vh_launch_split3_planes: bad argument");
+    hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)s, input,
+                       static_cast<__bf16 *>(planes), count);
+    VH_LAUNCH_CHECK("split3_planes_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_linear_w3(vh_stream_t s, float *output, const void *weight_planes, const float *input,
+                                   const float *bias, int rowA, int colA, int colB, int doGelu, const float *residual)
+{
+    if (!output || !weight_planes || !input || !bias)
+        return vh_fail(1, "vh_launch_linear_w3: null pointer argument");
+    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % BK != 0 || colB % 128 != 0)
+        return vh_fail(1, "vh_launch_linear_w3: needs colA %% 32 == 0 and colB %% 128 == 0 (%d,%d,%d)", rowA, colA, colB);
+    if (doGelu && residual)
+        return vh_fail(1, "vh_launch_linear_w3: GELU and residual together are not a model op");
+    GemmParams p = {};
+    p.A = input; p.W = weight_planes; p.bias = bias; p.R = residual; p.C = output;
+    p.M = rowA; p.N = colB; p.K = colA;
+    if (!aligned16(p) || (((uintptr_t)weight_planes | (uintptr_t)input) & 15) != 0)
+        return vh_fail(1, "vh_launch_linear_w3: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)s;
+    int c = cfg_override();
+    const bool resid_short_k = residual && colA < 2048;
+    if (c != 1 && c != 3)
+        c = (colB % 256 == 0 && rowA >= 4096 && !resid_short_k) ? 3 : 1;
+    if (c == 3 && colB % 256 != 0)
+        c = 1;
+#define VH_W3(EPI)                                                                        \
+    (c == 3 ? launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, true>(st, p)            \
+            : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, true>(st, p))
+    if (doGelu)
+        return VH_W3(EPI_GELU);
+    if (residual)
+        return VH_W3(EPI_RESID);
+    return VH_W3(EPI_NONE);
+#undef VH_W3
+}
 
 extern "C" int vh_launch_convert_fp8(vh_stream_t s, const float *input, void *output, size_t count, float multiplier)
 {
