@@ -135,6 +135,31 @@ __device__ __forceinline__ float gelu_exact(float x)
     return 0.5f * x * (1.0f + erf_a);
 }
 
+/* The same GELU on two values at once: every step is a packed instruction (v_pk_mul_f32,
+ * v_pk_fma_f32, ...), half the VALU issue slots of the scalar form, the same bits per element. */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_exact2(f32x2 x)
+{
+    const f32x2 a = x * 0.70710678118654752f;
+    const f32x2 t = __builtin_elementwise_min(__builtin_elementwise_abs(a), f32x2{4.0f, 4.0f});
+    auto k = [](float c) { return f32x2{c, c}; };
+    f32x2 s = k(-1.434945176e-07f);
+    s = __builtin_elementwise_fma(s, t, k(3.633770575e-06f));
+    s = __builtin_elementwise_fma(s, t, k(-4.095854820e-05f));
+    s = __builtin_elementwise_fma(s, t, k(2.688577224e-04f));
+    s = __builtin_elementwise_fma(s, t, k(-1.106124371e-03f));
+    s = __builtin_elementwise_fma(s, t, k(2.616208047e-03f));
+    s = __builtin_elementwise_fma(s, t, k(-3.566097876e-04f));
+    s = __builtin_elementwise_fma(s, t, k(-2.759680524e-02f));
+    s = __builtin_elementwise_fma(s, t, k(1.482741833e-01f));
+    s = __builtin_elementwise_fma(s, t, k(9.184474349e-01f));
+    s = __builtin_elementwise_fma(s, t, k(1.627907038e+00f));
+    const f32x2 ts = t * s;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-ts[0]), __builtin_amdgcn_exp2f(-ts[1])};
+    const f32x2 erf_a = __builtin_elementwise_copysign(k(1.0f) - e, a);
+    return (x * 0.5f) * (k(1.0f) + erf_a);
+}
+
 /* Exact 3-way bf16 split of eight fp32 values: x = p0 + p1 + p2 with p0 = bf16(x),
  * p1 = bf16(x - p0), p2 = bf16(x - p0 - p1); the subtractions are exact (Sterbenz / aligned
  * bits).  Left to the compiler's own pairing (v_cvt_pk_bf16_f32, part of the subtractions as
@@ -644,14 +669,123 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     };
 
     const int nk = p.K / KE;
-    stg.dma(p, smem, 0, 0, wave);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk)
-            stg.dma(p, smem, cur ^ 1, kt + 1, wave);
-        compute(cur);
+    if constexpr (W3) {
+        /* K loop pipelined across steps.  With the weights pre-split a step's only VALU work is
+         * the A splits, so the barrier can sit before the LAST fragment group (by then every
+         * wave has read all of tile t): behind that group's MFMAs the W fragments of tile t+1
+         * are fetched in place (W[j] is dead once its six MFMAs are issued) and A fragment 0 of
+         * tile t+1 is split -- the next step starts on its MFMAs at once. */
+        static_assert(IT >= 3, "pipeline depth");
+        const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
+        const int w3o = BM * BK + (wn * 16 * JT + l15) * 16 + 4 * (q ^ ((l15 >> 2) & 3));
+        bf16x8 w0[JT], w1[JT], w2[JT], c0, c1, c2;
+        f32x4 ra[2][2];
+        auto read_w = [&](const float *w3, int j) {
+            w0[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + j * 256));
+            w1[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + BN * 16 + j * 256));
+            w2[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + 2 * BN * 16 + j * 256));
+        };
+        auto read_a01 = [&](const float *ab) {
+            ra[0][0] = *reinterpret_cast<const f32x4 *>(ab + k0);
+            ra[0][1] = *reinterpret_cast<const f32x4 *>(ab + k1);
+            ra[1][0] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k0);
+            ra[1][1] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k1);
+        };
+        /* groups first .. IT-2: read fragment i+2, split fragment i+1, MFMAs of fragment i */
+        auto front = [&](const float *ab) {
+#pragma unroll
+            for (int i = 0; i < IT - 1; ++i) {
+                bf16x8 n0, n1, n2;
+                split8(ra[(i + 1) & 1][0], ra[(i + 1) & 1][1], n0, n1, n2);
+                if (i + 2 < IT) {
+                    ra[i & 1][0] = *reinterpret_cast<const f32x4 *>(ab + (i + 2) * 16 * BK + k0);
+                    ra[i & 1][1] = *reinterpret_cast<const f32x4 *>(ab + (i + 2) * 16 * BK + k1);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) {
+                        const bf16x8 wp = (t == 0 || t == 3 || t == 5) ? w0[j] : (t == 1) ? w2[j] : w1[j];
+                        const bf16x8 ap = (t == 0) ? c2 : (t == 2 || t == 3) ? c1 : c0;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp, ap, acc[i][j], 0, 0, 0);
+                    }
+                if (i + 2 < IT)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int r = 0; r < 6 * JT - 2; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SGB_V, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                c0 = n0;
+                c1 = n1;
+                c2 = n2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        stg.dma(p, smem, 0, 0, wave);
         __syncthreads();
+        if (nk > 1)
+            stg.dma(p, smem, 1, 1, wave);
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+            read_w(smem + w3o, j);
+        read_a01(a_lane);
+        split8(ra[0][0], ra[0][1], c0, c1, c2);
+        __builtin_amdgcn_sched_barrier(0);
+
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            front(a_lane + (kt & 1) * STG);
+            __syncthreads();                  /* tile kt read by every wave; tile kt+1 has landed */
+            if (kt + 2 < nk)
+                stg.dma(p, smem, kt & 1, kt + 2, wave);
+            const float *nx = smem + ((kt + 1) & 1) * STG;
+            bf16x8 n0, n1, n2;
+            read_a01(nx + (wm * 16 * IT + l15) * BK);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                f32x4 c = acc[IT - 1][j];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], c2, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j], c0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], c1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], c1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], c0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], c0, c, 0, 0, 0);
+                acc[IT - 1][j] = c;
+                read_w(nx + w3o, j);          /* in place: W(kt)[j] is dead from here on */
+            }
+            split8(ra[0][0], ra[0][1], n0, n1, n2);
+#pragma unroll
+            for (int r = 0; r < 6 * JT - 2; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SGB_V, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            c0 = n0;
+            c1 = n1;
+            c2 = n2;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        front(a_lane + ((nk - 1) & 1) * STG);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const bf16x8 wp = (t == 0 || t == 3 || t == 5) ? w0[j] : (t == 1) ? w2[j] : w1[j];
+                const bf16x8 ap = (t == 0) ? c2 : (t == 2 || t == 3) ? c1 : c0;
+                acc[IT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp, ap, acc[IT - 1][j], 0, 0, 0);
+            }
+    } else {
+        stg.dma(p, smem, 0, 0, wave);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk)
+                stg.dma(p, smem, cur ^ 1, kt + 1, wave);
+            compute(cur);
+            __syncthreads();
+        }
     }
 
 #pragma unroll
@@ -674,9 +808,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             if (FP8IN) /* undo the operand scales (per tensor for A, per output column for W), then the bias */
                 v = v * *reinterpret_cast<const f32x4 *>(p.col_scale + col) + *reinterpret_cast<const f32x4 *>(p.bias + col);
             if (EPI == EPI_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = gelu_exact(v[r]);
+                const f32x2 lo = gelu_exact2(f32x2{v[0], v[1]}), hi = gelu_exact2(f32x2{v[2], v[3]});
+                v = f32x4{lo[0], lo[1], hi[0], hi[1]};
             }
             if (EPI == EPI_RESID)
                 v = *reinterpret_cast<const f32x4 *>(p.R + orow * p.N + col) + v;
