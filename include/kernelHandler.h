@@ -119,12 +119,13 @@ int vh_launch_linear(vh_stream_t s, float *output, const float *weight, const fl
                      const float *bias, int rowA, int colA, int colB, int doGelu,
                      const float *residual);
 
-/* The same product with the weight pre-split: `weight_planes` is [3][colB][colA] bfloat16, the exact
- * three-way split w = p0 + p1 + p2 written once by vh_launch_split3_planes (the fp32 GEMM forms
+/* The same product with the weight pre-split: `weight_planes` holds the exact three-way split
+ * w = p0 + p1 + p2 as bfloat16, laid out [colA/32][3][colB][32] (K step, part, row, element: what one K
+ * step of a tile reads is contiguous), written once by vh_launch_split3_planes (the fp32 GEMM forms
  * every product from such parts on the bf16 matrix cores; splitting the constant operand ahead
  * of time leaves only the activations to split in the inner loop).  Same results as
  * vh_launch_linear bit for bit.  colB % 128 == 0. */
-int vh_launch_split3_planes(vh_stream_t s, const float *input, void *planes, size_t count);
+int vh_launch_split3_planes(vh_stream_t s, const float *weight, void *planes, int rows, int cols);
 int vh_launch_linear_w3(vh_stream_t s, float *output, const void *weight_planes, const float *input,
                         const float *bias, int rowA, int colA, int colB, int doGelu,
                         const float *residual);

@@ -93,9 +93,9 @@ def test_linear_presplit_weight_planes_matches_fp32_weights(pkg, device, oracle,
     r = oracle.synth_fill(M * N, 303, 1.0, 0.0).reshape(M, N)
     d_x, d_w, d_b, d_r = _dev(pkg, x), _dev(pkg, w), _dev(pkg, b), _dev(pkg, r)
     d_w3 = pkg.DeviceBuffer((3 * N * K + 1) // 2)
-    _launch(pkg, "vh_launch_split3_planes", None, d_w.ptr, d_w3.ptr, N * K)
-    planes = d_w3.to_numpy().view(np.uint16)[:3 * N * K].reshape(3, N * K)
-    parts = (planes.astype(np.uint32) << 16).view(np.float32)
+    _launch(pkg, "vh_launch_split3_planes", None, d_w.ptr, d_w3.ptr, N, K)
+    planes = d_w3.to_numpy().view(np.uint16)[:3 * N * K].reshape(K // 32, 3, N, 32)     # K step, part, row, element
+    parts = (planes.astype(np.uint32) << 16).view(np.float32).transpose(1, 2, 0, 3).reshape(3, N * K)
     assert np.array_equal(parts[0].astype(np.float64) + parts[1] + parts[2], w.astype(np.float64))   # exact split
     d_o1, d_o2 = pkg.DeviceBuffer(M * N), pkg.DeviceBuffer(M * N)
     _launch(pkg, "vh_launch_linear_w3", None, d_o1.ptr, d_w3.ptr, d_x.ptr, d_b.ptr, M, K, N, gelu, d_r.ptr if resid else None)

@@ -299,7 +299,8 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
             for (int k = 0; k < 4; ++k) {
                 const int idx = 4 + 12 * l + big[k];
                 ctx->w3[idx] = (char *)ctx->w3_slab + off3;
-                TRY(vh_launch_split3_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], networks[idx].size));
+                TRY(vh_launch_split3_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], (int)networks[idx + 1].size,
+                                            (int)(networks[idx].size / networks[idx + 1].size)));
                 off3 += align_up(networks[idx].size * 6, 256);
             }
     }

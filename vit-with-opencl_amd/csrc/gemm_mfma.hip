@@ -435,7 +435,11 @@ struct Staging {
             }
         }
         if constexpr (W3) {
-            /* p.W = [3][N][K] bf16 planes.  Piece pc = 16 rows x 64 B of one plane; lane fills
+            /* p.W = [K/32][3][N][32] bf16 (K step, plane, row): the 64 bytes a row contributes to
+             * one K step sit next to its neighbours', so a tile's W read of a step is 3 runs of
+             * BN*64 contiguous bytes -- whole cache lines.  (Plane-major [3][N][K] reads half a
+             * line per row and step and doubled the traffic beyond L2: measured.)
+             * Piece pc = 16 rows x 64 B of one plane; lane fills
              * physical 16-byte chunk (lane & 3) of row (lane >> 2) with logical chunk
              * phys ^ ((row >> 2) & 3) (64-byte rows: the 16 rows of a fragment read then hit
              * 16 distinct 16-byte slots of the bank row). */
@@ -444,7 +448,7 @@ struct Staging {
                 const int pc = wave * NWP + i, plane = pc / (T::BN / 16), rb = pc - plane * (T::BN / 16);
                 const int r = 16 * rb + (lane >> 2);
                 const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
-                w_src[i] = static_cast<const char *>(p.W) + (((size_t)plane * p.N + n0 + r) * p.K) * 2 + 16 * chunk;
+                w_src[i] = static_cast<const char *>(p.W) + ((size_t)plane * p.N + n0 + r) * 64 + 16 * chunk;
             }
         } else {
 #pragma unroll
@@ -474,7 +478,7 @@ struct Staging {
         }
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (size_t)kt * (W3 ? 64 : 128)),
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (size_t)kt * (W3 ? (size_t)192 * p.N : (size_t)128)),
                                              (lptr_t)(Ws + (wave * NWP + i) * 8 * BK), 16, 0, 0);
     }
 };
@@ -1158,29 +1162,33 @@ namespace {
 
 /* fp32 [n] -> three bf16 planes [3][n]: x = p0 + p1 + p2 exactly (the SPLIT3 parts), done once
  * for the weights so that the GEMM's inner loop splits only the activations. */
-__global__ void split3_planes_kernel(const float *__restrict__ in, __bf16 *__restrict__ out, size_t n)
+__global__ void split3_planes_kernel(const float *__restrict__ in, __bf16 *__restrict__ out, int N, int K)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    if (i >= (size_t)N * K)
         return;
+    const int n = (int)(i / K), k = (int)(i - (size_t)n * K);
     const float x = in[i];
     const __bf16 h = (__bf16)x;
     const float r1 = x - (float)h;
     const __bf16 m = (__bf16)r1;
     const float r2 = r1 - (float)m;
-    out[i] = h;
-    out[n + i] = m;
-    out[2 * n + i] = (__bf16)r2;
+    /* [K/32][3][N][32]: K step, plane, row, element (see Staging) */
+    const size_t o = (((size_t)(k >> 5) * 3) * N + n) * 32 + (k & 31), plane = (size_t)N * 32;
+    out[o] = h;
+    out[o + plane] = m;
+    out[o + 2 * plane] = (__bf16)r2;
 }
 
 } // namespace
 
-extern "C" int vh_launch_split3_planes(vh_stream_t s, const float *input, void *planes, size_t count)
+extern "C" int vh_launch_split3_planes(vh_stream_t s, const float *weight, void *planes, int rows, int cols)
 {
-    if (!input || !planes || count == 0)
-        return vh_fail(1, "vh_launch_split3_planes: bad argument");
-    hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)s, input,
-                       static_cast<__bf16 *>(planes), count);
+    if (!weight || !planes || rows <= 0 || cols <= 0 || cols % BK != 0)
+        return vh_fail(1, "vh_launch_split3_planes: bad argument (cols must be a multiple of %d)", BK);
+    const size_t count = (size_t)rows * cols;
+    hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)s, weight,
+                       static_cast<__bf16 *>(planes), rows, cols);
     VH_LAUNCH_CHECK("split3_planes_kernel");
     return 0;
 }

@@ -130,7 +130,7 @@ def lib() -> C.CDLL:
     L.vh_launch_layer_norm.argtypes = [voidp] + [voidp] * 4 + [i, i, C.c_long, C.c_long, C.c_double]
     L.vh_launch_linear.argtypes = [voidp] + [voidp] * 4 + [i, i, i, i, voidp]
     L.vh_launch_attention.argtypes = [voidp, voidp, voidp, i, i, i, i]
-    L.vh_launch_split3_planes.argtypes = [voidp, voidp, voidp, sz]
+    L.vh_launch_split3_planes.argtypes = [voidp, voidp, voidp, i, i]
     L.vh_launch_linear_w3.argtypes = [voidp] + [voidp] * 4 + [i, i, i, i, voidp]
     L.vh_launch_softmax.argtypes = [voidp, voidp, voidp, i, i]
     L.vit_config_preset.argtypes = [C.POINTER(VitConfig), C.c_char_p]
