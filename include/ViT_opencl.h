@@ -136,6 +136,10 @@ enum vit_op_class
 };
 int vit_hip_profile_enable(vit_hip_ctx *ctx, int max_forwards);
 int vit_hip_profile_read(vit_hip_ctx *ctx, double ms_sum[VIT_OP_COUNT], long launches[VIT_OP_COUNT]);
+/* Record only the operator classes in `op_mask` (bit i = vit_op_class i; 0 = all).  Two event
+ * packets per recorded launch sit between kernels and cost ~2 % of a step when every launch is
+ * recorded; a throughput run records the one kernel its roofline is quoted on. */
+int vit_hip_profile_select(vit_hip_ctx *ctx, unsigned op_mask);
 
 /* Deterministic synthetic data (counter-based integer PRNG -> exact fp32; no
  * libm): dst[i] = offset + scale * u_i, u_i uniform in [-1,1) on a 2^-23 grid,

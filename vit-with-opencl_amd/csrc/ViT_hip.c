@@ -85,11 +85,14 @@ struct vit_hip_ctx
     int *prof_class;       /* operator class per recorded launch */
     int prof_cap;          /* launches the pool can hold */
     int prof_used;         /* launches recorded since enable */
+    unsigned prof_mask;    /* operator classes to record (bit = vit_op_class); 0 = all */
 };
 
 static int prof_begin(vit_hip_ctx *ctx, vh_stream_t s, int op_class)
 {
     if (!ctx->prof_ev || ctx->prof_used >= ctx->prof_cap)
+        return -1;
+    if (ctx->prof_mask && !(ctx->prof_mask & (1u << op_class)))
         return -1;
     const int slot = ctx->prof_used++;
     ctx->prof_class[slot] = op_class;
@@ -543,6 +546,16 @@ int vit_hip_profile_enable(vit_hip_ctx *ctx, int max_forwards)
 fail:
     prof_release(ctx);
     return rc;
+}
+
+/* Restrict recording to the operator classes in `op_mask` (bit i = vit_op_class i; 0 = all): every
+ * recorded launch costs two event packets between kernels, which a timed run may not want. */
+int vit_hip_profile_select(vit_hip_ctx *ctx, unsigned op_mask)
+{
+    if (!ctx)
+        return 1;
+    ctx->prof_mask = op_mask;
+    return 0;
 }
 
 int vit_hip_profile_read(vit_hip_ctx *ctx, double ms_sum[VIT_OP_COUNT], long launches[VIT_OP_COUNT])

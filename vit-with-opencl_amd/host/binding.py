@@ -33,7 +33,7 @@ EXPORTS = [
     "vit_config_preset", "vit_config_tokens", "vit_config_num_tensors", "vit_config_tensor_size",
     "ViT_opencl", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
     "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
-    "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_create_ex", "vit_hip_precision",
+    "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_profile_select", "vit_hip_create_ex", "vit_hip_precision",
     "vh_launch_convert_bf16", "vh_launch_layer_norm_bf16", "vh_launch_linear_bf16", "vh_launch_attention_bf16",
     "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_launch_split3_planes", "vh_launch_linear_w3",
     "vh_launch_convert_fp8", "vh_launch_quantize_rows_fp8", "vh_launch_absmax", "vh_launch_scale_vector",
@@ -167,6 +167,7 @@ def lib() -> C.CDLL:
     L.vit_hip_weight.restype = voidp
     L.vit_hip_read_tokens.argtypes = [voidp, i, f32p]
     L.vit_hip_profile_enable.argtypes = [voidp, i]
+    L.vit_hip_profile_select.argtypes = [voidp, C.c_uint]
     L.vit_hip_profile_read.argtypes = [voidp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.vit_synth_fill.argtypes = [f32p, sz, C.c_ulonglong, C.c_float, C.c_float]
     L.vit_synth_fill.restype = None
@@ -338,6 +339,11 @@ class ViTHip:
 
     def profile_enable(self, max_forwards: int):
         check(self.L.vit_hip_profile_enable(self.ctx, max_forwards), "vit_hip_profile_enable")
+
+    def profile_select(self, names=None):
+        """Record only these operators (names from OP_NAMES); None = all."""
+        mask = 0 if not names else sum(1 << self.OP_NAMES.index(n) for n in names)
+        check(self.L.vit_hip_profile_select(self.ctx, mask), "vit_hip_profile_select")
 
     def profile_read(self) -> dict[str, tuple[float, int]]:
         """-> {operator: (summed ms, launches)} since the last read."""
