@@ -87,24 +87,15 @@ int main(int argc, char **argv)
     for (int i = 0; i < n; ++i)
         probabilities[i] = (float *)malloc(sizeof(float) * NUM_CLASSES);
 
-    FILE *out = fopen(result_file, "w");
-    if (!out) {
-        fprintf(stderr, "cannot open %s for writing\n", result_file);
-        return 100;
-    }
     printf("=====================Start========================\n");
     const double t0 = wall();
     ViT_opencl(images, network, probabilities);
     printf("Elapsed time: %.4f sec\n", wall() - t0);
 
-    for (int i = 0; i < n; ++i) {
-        int pred = 0;
-        for (int j = 1; j < NUM_CLASSES; ++j)
-            if (probabilities[i][j] > probabilities[i][pred])
-                pred = j;
-        fprintf(out, "[%d] label: %d / prob: %.6f\n", i, pred, probabilities[i][pred]);
+    if (vit_write_result_file(result_file, probabilities, n, NUM_CLASSES) != 0) {
+        fprintf(stderr, "cannot write %s\n", result_file);
+        return 100;
     }
-    fclose(out);
 
     const int errors = compare_files(result_file, answer_file, n);
     if (errors == 0)

@@ -141,6 +141,22 @@ int vit_hip_profile_read(vit_hip_ctx *ctx, double ms_sum[VIT_OP_COUNT], long lau
  * recorded; a throughput run records the one kernel its roofline is quoted on. */
 int vit_hip_profile_select(vit_hip_ctx *ctx, unsigned op_mask);
 
+/* Result file in Main.c's format (Main.c:59-72: "[%d] label: %d / prob: %.6f", arg-max restarted
+ * per image) and a comparison stricter than comparator.c:74-86 (label equal and |dprob| <= 0.01):
+ * largest / mean absolute difference, top-1 agreement, top-1 agreement not counting rows whose
+ * reference margin between the two classes is within twice `tolerance`, mean
+ * top-5 overlap, and the number of non-finite differences.  `got` / `want` are [rows][classes]. */
+typedef struct {
+    int rows, classes;
+    double max_abs_diff, mean_abs_diff;
+    int top1_equal, top1_equal_or_near_tie;
+    double top5_overlap;
+    int nonfinite;
+} vit_compare_report;
+int vit_write_result_file(const char *path, float *const *probabilities, int n, int classes);
+int vit_compare_rows(const float *got, const float *want, int n, int classes, double tolerance,
+                     vit_compare_report *rep);
+
 /* Deterministic synthetic data (counter-based integer PRNG -> exact fp32; no
  * libm): dst[i] = offset + scale * u_i, u_i uniform in [-1,1) on a 2^-23 grid,
  * fully determined by (seed, i).  Shared by tests, bench and the oracle

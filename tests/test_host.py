@@ -198,3 +198,37 @@ def test_fp8_reference_round_trips_every_code():
     assert np.array_equal(back[keep] & 0x7f, codes[keep] & 0x7f) and np.array_equal(back[keep] >> 7, codes[keep] >> 7)
     assert fp8_ref.dequantize(fp8_ref.quantize(np.array([1e9, -1e9, 448.0, 464.0], np.float32))).tolist() == [448.0, -448.0, 448.0, 448.0]
     assert fp8_ref.quantize(np.array([1.0625, 1.1875, 2.0 ** -10], np.float32)).tolist() == [56, 58, 0]
+
+
+def test_result_file_and_strict_comparison(pkg, tmp_path):
+    """vit_write_result_file writes Main.c's line format with a per-image arg-max (class 0 does not
+    leak between images as with Main.c:59's pred_idx); vit_compare_rows reports what comparator.c's
+    0.01 check hides."""
+    import ctypes as C
+    L, b = pkg.lib(), pkg.binding
+    rng = np.random.default_rng(5)
+    want = rng.standard_normal((6, 1000)).astype(np.float32)
+    want[2, 0] = 9.0                       # image 2 predicts class 0 after image 1 predicted class 7
+    want[1, 7] = 9.0
+    rows = (b.f32p * 6)(*[b.fptr(want[i]) for i in range(6)])
+    path = tmp_path / "result.txt"
+    assert L.vit_write_result_file(str(path).encode(), rows, 6, 1000) == 0
+    lines = path.read_text().splitlines()
+    assert lines[1] == "[1] label: 7 / prob: 9.000000" and lines[2] == "[2] label: 0 / prob: 9.000000"
+    assert [int(l.split("label:")[1].split("/")[0]) for l in lines] == want.argmax(1).tolist()
+
+    got = want + rng.uniform(-1e-3, 1e-3, want.shape).astype(np.float32)
+    got[4, want[4].argmax()] -= 50.0       # a real top-1 error
+    a, c = np.sort(want[5])[-1], np.sort(want[5])[-2]
+    i1, i2 = want[5].argmax(), np.argsort(want[5])[-2]
+    want[5, i2] = want[5, i1] - 1e-4       # a near tie in the reference ...
+    got[5] = want[5]
+    got[5, i2] += 3e-4                     # ... flipped by an error of its own size
+    rep = b.CompareReport()
+    assert L.vit_compare_rows(b.fptr(got), b.fptr(want), 6, 1000, 3e-4, C.byref(rep)) == 0
+    assert rep.rows == 6 and rep.classes == 1000 and rep.nonfinite == 0
+    assert abs(rep.max_abs_diff - 50.0) < 1e-2
+    assert rep.top1_equal == 4 and rep.top1_equal_or_near_tie == 5
+    assert 0.9 < rep.top5_overlap <= 1.0
+    got[0, 3] = np.nan
+    assert L.vit_compare_rows(b.fptr(got), b.fptr(want), 6, 1000, 3e-4, C.byref(rep)) == 0 and rep.nonfinite == 1

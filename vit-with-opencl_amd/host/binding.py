@@ -40,6 +40,7 @@ EXPORTS = [
     "vh_launch_layer_norm_fp8", "vh_launch_linear_fp8", "vit_hip_calibrate_fp8", "vit_hip_fp8_scales",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
     "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
+    "vit_write_result_file", "vit_compare_rows",
 ]
 
 
@@ -51,6 +52,13 @@ class VitConfig(C.Structure):
         ("num_classes", C.c_int), ("embed_dim", C.c_int), ("depth", C.c_int),
         ("num_heads", C.c_int), ("mlp_hidden", C.c_int), ("eps", C.c_double),
     ]
+
+
+class CompareReport(C.Structure):
+    """`vit_compare_report` (include/ViT_opencl.h)."""
+    _fields_ = [("rows", C.c_int), ("classes", C.c_int), ("max_abs_diff", C.c_double), ("mean_abs_diff", C.c_double),
+                ("top1_equal", C.c_int), ("top1_equal_or_near_tie", C.c_int), ("top5_overlap", C.c_double),
+                ("nonfinite", C.c_int)]
 
 
 class ImageData(C.Structure):
@@ -181,6 +189,8 @@ def lib() -> C.CDLL:
     L.load_weights.restype = None
     L.vit_write_image_file.argtypes = [C.c_char_p, C.POINTER(ImageData), i]
     L.vit_write_weight_file.argtypes = [C.c_char_p, i, C.c_char_p, f32p, sz]
+    L.vit_write_result_file.argtypes = [C.c_char_p, C.POINTER(f32p), i, i]
+    L.vit_compare_rows.argtypes = [f32p, f32p, i, i, C.c_double, C.POINTER(CompareReport)]
     _lib = L
     return L
 
