@@ -93,7 +93,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "fp8"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "fp8", "f32_fp16x2"], default="f32",
                     help="f32 = the parity path (default, what `value` is quoted on); bf16 = bf16-operand GEMMs "
                          "(BASELINE config 3; logits ~1e-2 from ViT_seq.c, so never the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -198,28 +198,38 @@ def main() -> None:
 
     # Secondary leg (N=1, default dtype only): the same step with bf16-operand GEMMs, reported
     # beside -- never instead of -- the fp32 `value`.
-    bf16_leg = None
-    if comm is None and args.dtype == "f32":
-        m16 = pkg.ViTHip(cfg, weights, device=device, max_batch=B, precision="bf16")
-        d_l16 = pkg.DeviceBuffer(B * NC)
+    bf16_leg = emu_leg = None
+
+    def secondary(precision, label):
+        m2 = pkg.ViTHip(cfg, weights, device=device, max_batch=B, precision=precision)
+        d_l2 = pkg.DeviceBuffer(B * NC)
         for _ in range(2):
-            m16.forward_device(d_images.ptr, B, d_l16.ptr, d_probs.ptr, m16.stream)
+            m2.forward_device(d_images.ptr, B, d_l2.ptr, d_probs.ptr, m2.stream)
         pkg.binding.check(L.vh_device_sync(), "sync")
-        m16.profile_enable(5)
-        t16 = time.perf_counter()
+        t2 = time.perf_counter()
         for _ in range(5):
-            m16.forward_device(d_images.ptr, B, d_l16.ptr, d_probs.ptr, m16.stream)
+            m2.forward_device(d_images.ptr, B, d_l2.ptr, d_probs.ptr, m2.stream)
         pkg.binding.check(L.vh_device_sync(), "sync")
-        dt16 = (time.perf_counter() - t16) / 5
-        p16 = m16.profile_read()
-        l16 = d_l16.to_numpy((B, NC))
+        dt2 = (time.perf_counter() - t2) / 5
+        m2.profile_enable(2)
+        for _ in range(2):
+            m2.forward_device(d_images.ptr, B, d_l2.ptr, d_probs.ptr, m2.stream)
+        pkg.binding.check(L.vh_device_sync(), "sync")
+        p2 = m2.profile_read()
+        l2 = d_l2.to_numpy((B, NC))
         l32 = d_logits.to_numpy((B, NC))
-        bf16_leg = {"dtype": "bf16 GEMM operands, fp32 accumulate/residual/attention", "value": round(B / dt16, 1),
-                    "unit": "images/sec", "ms_per_step": round(dt16 * 1e3, 3),
-                    "max_abs_dlogit_vs_f32_path": float(np.abs(l16 - l32).max()),
-                    "argmax_agreement_with_f32_path": float((l16.argmax(1) == l32.argmax(1)).mean()),
-                    "kernels_avg_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in p16.items() if cnt}}
-        m16.close()
+        m2.close()
+        return ({"dtype": label, "value": round(B / dt2, 1), "unit": "images/sec", "ms_per_step": round(dt2 * 1e3, 3),
+                 "max_abs_dlogit_vs_f32_path": float(np.abs(l2 - l32).max()),
+                 "argmax_agreement_with_f32_path": float((l2.argmax(1) == l32.argmax(1)).mean()),
+                 "kernels_avg_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in p2.items() if cnt}}, l2)
+
+    emu_logits0 = None
+    if comm is None and args.dtype == "f32":
+        bf16_leg, _ = secondary("bf16", "bf16 GEMM operands, fp32 accumulate/residual/attention")
+        emu_leg, emu_l = secondary("f32_fp16x2", "fp32 operands emulated with two fp16 parts and three fp16 MFMAs per "
+                                   "product (22 of 24 significand bits; NOT exact), everything else as the fp32 path")
+        emu_logits0 = emu_l[0]
         # restore the fp32 path's probabilities for the checks below
         model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
         pkg.binding.check(L.vh_device_sync(), "sync")
@@ -253,7 +263,9 @@ def main() -> None:
         # fp32 products are formed on the bf16 cores from an exact 3-way split (6 bf16 MFMAs per
         # product block, gemm_mfma.hip SPLIT3), unless VIT_HIP_GEMM_FP32=native selects the fp32 MFMA.
         native = os.environ.get("VIT_HIP_GEMM_FP32", "split3").startswith("n")
-        if args.dtype != "f32":
+        if args.dtype == "f32_fp16x2":
+            peak_tf, peak_note = 2500.0 / 3.0, "dense fp16 MFMA peak / 3: three fp16 MFMAs per emulated fp32 product block"
+        elif args.dtype != "f32":
             peak_tf, peak_note = 2500.0, "dense bf16 MFMA (non-scaled fp8 MFMA runs at the same rate)"
         elif native:
             peak_tf, peak_note = PEAK_F32_MFMA_TFLOPS, "native fp32 MFMA (v_mfma_f32_32x32x2_f32)"
@@ -275,6 +287,8 @@ def main() -> None:
                      "native fp32 MFMA (v_mfma_f32_32x32x2_f32), Tile<256,256,4,4>" if native else
                      "bf16 operands on v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16" else
                      "e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8" if args.dtype == "fp8" else
+                     "fp32 operands as two fp16 parts, 3 x v_mfma_f32_16x16x32_f16 per block (not exact)"
+                     if args.dtype == "f32_fp16x2" else
                      "exact 3-way bf16 split of fp32 operands, 6 x v_mfma_f32_16x16x32_bf16 per block"),
                     "peak_basis": peak_note,
                     "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
@@ -300,6 +314,8 @@ def main() -> None:
             "gemm_arithmetic": ("bf16 operands, fp32 accumulate" if args.dtype == "bf16" else
                                 "e4m3 operands (per-row weight scales, per-tensor activation scales), fp32 accumulate"
                                 if args.dtype == "fp8" else
+                                "fp32 operands as two fp16 parts (22 significant bits), 3 fp16 MFMAs per product, fp32 accumulate"
+                                if args.dtype == "f32_fp16x2" else
                                 "fp32 (native fp32 MFMA)" if native else
                                 "fp32 operands split exactly into 3 bf16 parts, 6 bf16 MFMAs per product, fp32 accumulate"),
             "model_tflops": round(total_flops * B * args.steps * world / elapsed / 1e12, 2),
@@ -310,6 +326,8 @@ def main() -> None:
         }
         if bf16_leg is not None:
             out["bf16_gemm_mode"] = bf16_leg
+        if emu_leg is not None:
+            out["fp32_fp16x2_emulation_mode"] = emu_leg
         if world == 1 and not args.no_cpu_baseline and args.model == "vit_b_16":
             nproc = args.cpu_procs or max(1, min(os.cpu_count() or 1, 16))
             base, ref_logits = cpu_baseline(nproc)
@@ -318,6 +336,8 @@ def main() -> None:
                 out["parity"] = {"max_abs_dlogit_vs_ViT_seq": float(np.abs(logits0 - ref_logits).max()),
                                  "argmax_equal": bool(int(logits0.argmax()) == int(ref_logits.argmax())),
                                  "tolerance": 1e-4, "image": 0}
+                if emu_leg is not None:
+                    emu_leg["max_abs_dlogit_vs_ViT_seq"] = float(np.abs(emu_logits0 - ref_logits).max())
         out["checks"] = {"logits_finite": bool(np.isfinite(logits0).all()),
                          "prob_sum_image0": float(probs0.sum())}
         print(json.dumps(out), flush=True)

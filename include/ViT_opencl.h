@@ -78,7 +78,7 @@ void vit_hip_destroy(vit_hip_ctx *ctx);
  * arithmetic, norms and classifier stay fp32.  Its logits differ from ViT_seq.c by
  * ~1e-2 (tests/test_gpu_parity.py states the tolerance), so it is opt-in:
  * vit_hip_create() uses F32 unless $VIT_HIP_PRECISION=bf16. */
-enum { VIT_PRECISION_F32 = 0, VIT_PRECISION_BF16_GEMM = 1, VIT_PRECISION_FP8_GEMM = 2 };
+enum { VIT_PRECISION_F32 = 0, VIT_PRECISION_BF16_GEMM = 1, VIT_PRECISION_FP8_GEMM = 2, VIT_PRECISION_F32_FP16X2 = 3 };
 int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                       int n_tensors, int device, int max_batch, int precision);
 int vit_hip_precision(const vit_hip_ctx *ctx);
@@ -92,6 +92,12 @@ int vit_hip_precision(const vit_hip_ctx *ctx);
  * records max |x| of every GEMM input.  Logits differ from ViT_seq.c at the 1e-1 level
  * (3-bit significands; tools/quant_report.py prints the per-layer error), so: opt-in only. */
 int vit_hip_calibrate_fp8(vit_hip_ctx *ctx, const float *d_images, int n);
+
+/* F32_FP16X2: everything as in F32 except that the four big projections emulate the fp32 product
+ * with two fp16 parts per operand and three matrix-core products (vh_launch_linear_h2) instead of
+ * the exact three-part / six-product split.  Operands keep 22 of 24 significant bits; measured
+ * class logits stay within the fp32 path's own tolerance of ViT_seq.c (1e-4; tests/test_gpu_parity.py),
+ * but it is not an exact fp32 product, so: opt-in, never what `ViT_opencl` uses. */
 int vit_hip_fp8_scales(const vit_hip_ctx *ctx, float *out, int capacity);
 
 /* Host-pointer forward: gathers the n separately allocated images into pinned

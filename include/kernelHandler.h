@@ -130,6 +130,18 @@ int vh_launch_linear_w3(vh_stream_t s, float *output, const void *weight_planes,
                         const float *bias, int rowA, int colA, int colB, int doGelu,
                         const float *residual);
 
+/* fp32 emulation with two fp16 parts per operand and three products (the "3 x TF32" scheme on
+ * fp16: a = a0 + a1 + eps, |eps| <= 2^-22 |a|; a.w ~ a0w0 + a0w1 + a1w0, fp32 accumulation).  NOT
+ * exact -- operands keep 22 of their 24 significant bits -- but its truncation error (~8e-8 of the
+ * result) is an order of magnitude below the rounding noise of an fp32 accumulation, at half
+ * the matrix-core work of the exact split.  `weight_planes` = [colA/32][2][colB][32] fp16 of
+ * weight * weight_scale (a power of two that lifts the low part out of fp16's subnormal range;
+ * vh_launch_split2h_planes); inputs must stay below 65504 in magnitude.  Opt-in (ViT_opencl.h). */
+int vh_launch_split2h_planes(vh_stream_t s, const float *weight, void *planes, int rows, int cols, float scale);
+int vh_launch_linear_h2(vh_stream_t s, float *output, const void *weight_planes, float weight_scale,
+                        const float *input, const float *bias, int rowA, int colA, int colB,
+                        int doGelu, const float *residual);
+
 /* Scaled-dot-product attention over the fused QKV rows produced by
  * vh_launch_linear (row = Q[embed] | K[embed] | V[embed]); per (image, head):
  * softmax(Q K^T / sqrt(head_dim)) V, heads concatenated.  Replaces

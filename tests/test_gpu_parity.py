@@ -111,6 +111,38 @@ def test_linear_presplit_weight_planes_matches_fp32_weights(pkg, device, oracle,
         assert np.abs(got - want).max() <= OP_TOL
 
 
+@pytest.mark.parametrize("M,K,N,gelu,resid", [
+    (197, 768, 2304, 0, False), (197, 768, 768, 0, True), (300, 768, 3072, 1, False), (300, 3072, 768, 0, True),
+    (4300, 768, 3072, 1, False),       # the 256x256-tile path (M >= 4096): checked on a row sample
+])
+def test_linear_fp16x2_emulation_vs_oracle(pkg, device, oracle, M, K, N, gelu, resid):
+    """vh_launch_linear_h2: fp32 product emulated with two fp16 parts per operand and three
+    matrix-core products.  Not exact (22 of 24 significand bits), but it must meet the SAME
+    operator tolerance as the exact path: its truncation error is ~8e-8 of the result."""
+    x = oracle.synth_fill(M * K, 310 + M, 1.0, 0.1).reshape(M, K)
+    w = oracle.synth_fill(N * K, 311 + N, 0.04, 0.0)
+    b = oracle.synth_fill(N, 312, 0.1, 0.0)
+    r = oracle.synth_fill(M * N, 313, 1.0, 0.0).reshape(M, N)
+    scale = 2.0 ** 18                                     # 0.04 * 2^18 ~ 10486: inside [8192, 16384)
+    d_x, d_w, d_b, d_r = _dev(pkg, x), _dev(pkg, w), _dev(pkg, b), _dev(pkg, r)
+    d_w2 = pkg.DeviceBuffer(N * K)
+    _launch(pkg, "vh_launch_split2h_planes", None, d_w.ptr, d_w2.ptr, N, K, scale)
+    planes = d_w2.to_numpy().view(np.float16)[:2 * N * K].reshape(K // 32, 2, N, 32).transpose(1, 2, 0, 3).reshape(2, N * K)
+    rec = (planes[0].astype(np.float64) + planes[1].astype(np.float64)) / scale
+    assert np.abs(rec - w).max() <= 2.0 ** -21 * np.abs(w).max()           # two parts: 22 bits
+    d_o = pkg.DeviceBuffer(M * N)
+    _launch(pkg, "vh_launch_linear_h2", None, d_o.ptr, d_w2.ptr, scale, d_x.ptr, d_b.ptr, M, K, N, gelu,
+            d_r.ptr if resid else None)
+    got = d_o.to_numpy((M, N))
+    rows = np.arange(M) if M <= 300 else np.r_[0:40, 2000:2040, M - 40:M]
+    want = oracle.linear(x[rows], w, b, N)
+    if gelu:
+        want = oracle.gelu(want.ravel()).reshape(len(rows), N)
+    if resid:
+        want = r[rows] + want
+    assert np.abs(got[rows] - want).max() <= OP_TOL
+
+
 def test_linear_rejects_bad_arguments(pkg, device):
     L = pkg.lib()
     d = pkg.DeviceBuffer(1024)
@@ -533,6 +565,24 @@ def test_model_bf16_gemm_mode(pkg, device, weights, golden_full):
     srt = np.sort(ref, axis=1)
     clear = (srt[:, -1] - srt[:, -2]) > 8e-2
     assert np.array_equal(logits.argmax(1)[clear], ref.argmax(1)[clear]) and clear.any()
+
+
+def test_model_fp32_emulated_with_fp16_pairs_meets_the_fp32_tolerance(pkg, device, weights, golden_full):
+    """VIT_PRECISION_F32_FP16X2 (opt-in): the projections on two fp16 parts / three products.  Same
+    stated tolerance as the exact fp32 path -- class logits within 1e-4 of the reference's ViT_seq.c,
+    same arg-max, probabilities within 1e-6 -- plus batch-position independence."""
+    cfg = pkg.preset("vit_b_16")
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=8, precision="f32_fp16x2")
+    imgs = pkg.synth_images(cfg, 0, 4)
+    logits, probs = m.forward(imgs)
+    l2, _ = m.forward(np.concatenate([imgs[2:3], imgs[0:1]]))
+    m.close()
+    err = np.abs(logits - golden_full["logits"][:4]).max()
+    print("fp16x2 emulation: max |dlogit| vs ViT_seq.c", err)
+    assert err <= LOGIT_TOL
+    assert np.array_equal(logits.argmax(1), golden_full["logits"][:4].argmax(1))
+    assert np.abs(probs - golden_full["probs"][:4]).max() <= 1e-6
+    assert np.array_equal(l2[0], logits[2]) and np.array_equal(l2[1], logits[0])
 
 
 # ---- fp8-operand GEMM mode (BASELINE config 5) ---------------------------------------

@@ -20,6 +20,7 @@
  */
 #include "ViT_opencl.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -53,6 +54,7 @@ struct vit_hip_ctx
     /* F32: the same four matrices pre-split into three bf16 planes each (vh_launch_linear_w3) */
     void *w3_slab;
     void **w3;          /* per tensor index (NULL: use the fp32 tensor) */
+    float *w3_scale;    /* F32_FP16X2: per tensor index, the power of two its fp16 parts were scaled by */
     void *w8_slab;
     void **w8;          /* per tensor index */
     float *wscale_slab; /* per tensor index: [out_features] row scales, then [out_features] a_scale*row scale */
@@ -158,6 +160,7 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
     if (ctx->w3_slab)
         vh_free(ctx->w3_slab);
     free(ctx->w3);
+    free(ctx->w3_scale);
     if (ctx->w8_slab)
         vh_free(ctx->w8_slab);
     if (ctx->wscale_slab)
@@ -207,8 +210,11 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
     int rc = 0;
     if (!out || !cfg || !networks || max_batch <= 0)
         return 1;
-    if (precision != VIT_PRECISION_F32 && precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM)
+    if (precision != VIT_PRECISION_F32 && precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM &&
+        precision != VIT_PRECISION_F32_FP16X2)
         return 1;
+    if (precision == VIT_PRECISION_F32_FP16X2 && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
+        return 2;
     if (precision == VIT_PRECISION_FP8_GEMM && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
         return 2;
     *out = NULL;
@@ -237,14 +243,16 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
     ctx->w = (float **)calloc((size_t)n_tensors, sizeof(float *));
     ctx->w16 = (void **)calloc((size_t)n_tensors, sizeof(void *));
     ctx->w3 = (void **)calloc((size_t)n_tensors, sizeof(void *));
+    ctx->w3_scale = (float *)calloc((size_t)n_tensors, sizeof(float));
     ctx->w8 = (void **)calloc((size_t)n_tensors, sizeof(void *));
     ctx->wscale = (float **)calloc((size_t)n_tensors, sizeof(float *));
     ctx->colscale = (float **)calloc((size_t)n_tensors, sizeof(float *));
     ctx->act_scale = (float *)calloc((size_t)cfg->depth * 4, sizeof(float));
-    if (!ctx->w || !ctx->w16 || !ctx->w3 || !ctx->w8 || !ctx->wscale || !ctx->colscale || !ctx->act_scale) {
+    if (!ctx->w || !ctx->w16 || !ctx->w3 || !ctx->w3_scale || !ctx->w8 || !ctx->wscale || !ctx->colscale || !ctx->act_scale) {
         free(ctx->w);
         free(ctx->w16);
         free(ctx->w3);
+        free(ctx->w3_scale);
         free(ctx->w8);
         free(ctx->wscale);
         free(ctx->colscale);
@@ -306,6 +314,43 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
                                             (int)(networks[idx].size / networks[idx + 1].size)));
                 off3 += align_up(networks[idx].size * 6, 256);
             }
+    }
+
+    if (precision == VIT_PRECISION_F32_FP16X2) {
+        /* two fp16 parts of w * 2^k per weight (4 bytes), k per tensor such that max|w| * 2^k lands in
+         * [8192, 16384): the low part stays clear of fp16's subnormals, nothing overflows */
+        static const int big[4] = {2, 4, 8, 10};
+        size_t total3 = 0;
+        for (int l = 0; l < cfg->depth; ++l)
+            for (int k = 0; k < 4; ++k)
+                total3 += align_up(networks[4 + 12 * l + big[k]].size * 4, 256);
+        TRY(vh_malloc(&ctx->w3_slab, total3));
+        float *d_amax = NULL, amax = 0.0f;
+        TRY(vh_malloc((void **)&d_amax, sizeof(float)));
+        size_t off3 = 0;
+        for (int l = 0; l < cfg->depth && rc == 0; ++l)
+            for (int k = 0; k < 4 && rc == 0; ++k) {
+                const int idx = 4 + 12 * l + big[k];
+                const int out_f = (int)networks[idx + 1].size, in_f = (int)(networks[idx].size / networks[idx + 1].size);
+                if ((rc = vh_memset(d_amax, 0, sizeof(float), ctx->stream)) != 0 ||
+                    (rc = vh_launch_absmax(ctx->stream, ctx->w[idx], networks[idx].size, d_amax)) != 0 ||
+                    (rc = vh_d2h(&amax, d_amax, sizeof(float), ctx->stream)) != 0 ||
+                    (rc = vh_stream_sync(ctx->stream)) != 0)
+                    break;
+                int e = 0;
+                float scale = 1.0f;
+                if (amax > 0.0f && amax < 3.0e38f) {
+                    (void)frexpf(amax, &e);                 /* amax = m * 2^e, m in [0.5, 1) */
+                    scale = ldexpf(1.0f, 14 - e);           /* amax * scale in [8192, 16384) */
+                }
+                ctx->w3[idx] = (char *)ctx->w3_slab + off3;
+                ctx->w3_scale[idx] = scale;
+                rc = vh_launch_split2h_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], out_f, in_f, scale);
+                off3 += align_up(networks[idx].size * 4, 256);
+            }
+        vh_free(d_amax);
+        if (rc)
+            goto fail;
     }
 
     if (precision == VIT_PRECISION_FP8_GEMM) {
@@ -406,6 +451,19 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_fp8(s, ctx->x, lw[6], lw[7], ctx->y, 1.0f / as[2], rows, E, E, E, c->eps));
         OP(VIT_OP_FC1, vh_launch_linear_fp8(s, ctx->hid, 2, lw8[8], ctx->y, lw[9], cs[8], 1.0f / as[3], rows, E, F, 1, NULL));
         OP(VIT_OP_FC2, vh_launch_linear_fp8(s, ctx->x, 0, lw8[10], ctx->hid, lw[11], cs[10], 1.0f, rows, F, E, 0, ctx->x));
+    }
+    for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32_FP16X2; ++l) {
+        /* the fp32 layer with the four projections on two fp16 parts / three products */
+        float **lw = w + 4 + 12 * l;
+        void **l3 = ctx->w3 + 4 + 12 * l;
+        const float *ws = ctx->w3_scale + 4 + 12 * l;
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
+        OP(VIT_OP_QKV, vh_launch_linear_h2(s, ctx->qkv, l3[2], ws[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+        OP(VIT_OP_ATTENTION, vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+        OP(VIT_OP_OUT_PROJ, vh_launch_linear_h2(s, ctx->x, l3[4], ws[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
+        OP(VIT_OP_FC1, vh_launch_linear_h2(s, ctx->hid, l3[8], ws[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+        OP(VIT_OP_FC2, vh_launch_linear_h2(s, ctx->x, l3[10], ws[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
     }
     for (int l = 0; l < c->depth && mode == VIT_PRECISION_BF16_GEMM; ++l) {
         /* bf16 GEMM operands: y, attn and hid hold bf16 (same allocations, half used);

@@ -75,10 +75,11 @@ struct Tile {
     static constexpr int CHW = BN / 8 / NW;          /* 8-row DMA pieces per wave, W */
     static constexpr int STAGE_F = (BM + BN) * BK;   /* floats per LDS stage */
     static constexpr size_t LDS = sizeof(float) * 2 * STAGE_F;
-    /* W as three pre-split bf16 planes (W3): BN rows x 64 B per plane instead of BN x 128 B */
-    static constexpr int STAGE_F3 = (BM + BN + BN / 2) * BK;
-    static constexpr size_t LDS3 = sizeof(float) * 2 * STAGE_F3;
-    static constexpr int CHW3 = 3 * BN / 16 / NW;    /* 16-row DMA pieces of a W plane per wave */
+    /* W as NPL pre-split 16-bit planes (3 x bf16 or 2 x fp16): BN rows x 64 B per plane instead of
+     * BN x 128 B of fp32 */
+    static constexpr int stage_f(int npl) { return npl ? BM * BK + npl * BN * 16 : STAGE_F; }
+    static constexpr size_t lds(int npl) { return sizeof(float) * 2 * stage_f(npl); }
+    static constexpr int chw(int npl) { return npl ? npl * BN / 16 / NW : CHW; }   /* W DMA pieces per wave */
     static constexpr int WG_PER_CU = (2 * LDS <= 160 * 1024) ? 2 : 1;
     static constexpr int MIN_WAVES_PER_SIMD = WG_PER_CU * NW / 4;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "DMA pieces must divide evenly over waves");
@@ -89,6 +90,7 @@ struct GemmParams {
     const void *A, *W;        /* operands: fp32 or bf16, row-major [M][K] and [N][K] */
     const float *bias, *R, *pos;
     const float *col_scale;   /* fp8 operands: a_scale * w_scale[n], multiplies the raw sum */
+    float w_scale, inv_w_scale; /* fp16 weight parts: the power of two the weights were multiplied by, and its inverse */
     float out_scale;          /* fp8 output: multiplier applied before the cast (1 / scale of the next input) */
     void *C;                  /* output: fp32 or bf16 */
     int M, N, K;
@@ -408,10 +410,10 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
 /* Operand staging shared by the 16x16x32 kernel below: per-lane source addresses of the
  * 8-row LDS-DMA pieces (same LDS image as gemm_f32_kernel: 128-byte rows, chunk c of row r
  * at c ^ ((r >> 1) & 7)). */
-template <class T, int AMODE, int ES, bool W3 = false>
+template <class T, int AMODE, int ES, int NPL = 0>
 struct Staging {
-    static constexpr int NWP = W3 ? T::CHW3 : T::CHW;     /* W pieces per wave */
-    static constexpr int STAGE = W3 ? T::STAGE_F3 : T::STAGE_F;
+    static constexpr int NWP = T::chw(NPL);               /* W pieces per wave */
+    static constexpr int STAGE = T::stage_f(NPL);
     const char *a_src[T::CHA], *w_src[NWP];
     int a_k[T::CHA];
 
@@ -434,9 +436,9 @@ struct Staging {
                     (size_t)ow * p.patch);
             }
         }
-        if constexpr (W3) {
-            /* p.W = [K/32][3][N][32] bf16 (K step, plane, row): the 64 bytes a row contributes to
-             * one K step sit next to its neighbours', so a tile's W read of a step is 3 runs of
+        if constexpr (NPL != 0) {
+            /* p.W = [K/32][NPL][N][32] 16-bit (K step, plane, row): the 64 bytes a row contributes to
+             * one K step sit next to its neighbours', so a tile's W read of a step is NPL runs of
              * BN*64 contiguous bytes -- whole cache lines.  (Plane-major [3][N][K] reads half a
              * line per row and step and doubled the traffic beyond L2: measured.)
              * Piece pc = 16 rows x 64 B of one plane; lane fills
@@ -478,10 +480,53 @@ struct Staging {
         }
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (size_t)kt * (W3 ? (size_t)192 * p.N : (size_t)128)),
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (size_t)kt * (NPL ? (size_t)64 * NPL * p.N : (size_t)128)),
                                              (lptr_t)(Ws + (wave * NWP + i) * 8 * BK), 16, 0, 0);
     }
 };
+
+/* Parts of a split fp32 operand, per decomposition:
+ *   NPL = 3: x = p0 + p1 + p2 exactly, bf16 parts; six products (all of weight >= 2^-16)
+ *   NPL = 2: x = p0 + p1 + eps, fp16 parts (2 x 11 significant bits; |eps| <= 2^-22 |x|, fp16
+ *            subnormals are honoured by the conversion and by the MFMA: tools/f16_denorm_probe.hip);
+ *            three products p0q0 + p0q1 + p1q0 -- the "3 x TF32"-style emulation: its truncation
+ *            error (7.7e-8 of the result, tools/split3_numerics.py) is an order of magnitude below
+ *            the rounding noise of any fp32 accumulation order, but it is not exact. */
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+template <int NPL> struct PartT { typedef bf16x8 type; };
+template <> struct PartT<2> { typedef half8 type; };
+
+__device__ __forceinline__ void split_parts(const f32x4 &u, const f32x4 &v, bf16x8 (&o)[3])
+{
+    split8(u, v, o[0], o[1], o[2]);
+}
+__device__ __forceinline__ void split_parts(const f32x4 &u, const f32x4 &v, half8 (&o)[2])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? u[e] : v[e - 4];
+        const _Float16 h = (_Float16)x;
+        o[0][e] = h;
+        o[1][e] = (_Float16)(x - (float)h);
+    }
+}
+__device__ __forceinline__ f32x4 mfma_part(bf16x8 w, bf16x8 a, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_part(half8 w, half8 a, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, a, c, 0, 0, 0);
+}
+/* (w part, a part) of product t, smallest terms first */
+template <int NPL> __device__ __forceinline__ constexpr int term_w(int t)
+{
+    return NPL == 3 ? (t == 0 || t == 3 || t == 5 ? 0 : t == 1 ? 2 : 1) : (t == 0 ? 1 : 0);
+}
+template <int NPL> __device__ __forceinline__ constexpr int term_a(int t)
+{
+    return NPL == 3 ? (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0) : (t == 1 ? 1 : 0);
+}
 
 /* The same GEMM on v_mfma_f32_16x16x32_bf16 (SPLIT3 for fp32 operands, or bf16 operands).
  * Under an MFMA-dense load the chip holds a higher clock on the 16x16x32 shape than on
@@ -491,7 +536,7 @@ struct Staging {
  * row: lane l holds out[m = i*16 + (l & 15)][n = j*16 + 4*(l >> 4) + r], r = 0..3, and the
  * bias, residual, position-embedding reads and the store are one 16-byte access each.
  * Operand fragment: lane l holds k = 8*(l >> 4) .. +7 of row (l & 15), natural k order. */
-template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false, bool W3 = false>
+template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false, int NPL = 0>
 __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel(const GemmParams p)
 {
     constexpr int BM = T::BM, BN = T::BN;
@@ -512,17 +557,19 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / T::WN, wn = wave % T::WN, l15 = lane & 15, q = lane >> 4;
 
-    static_assert(!W3 || (SCHED && INK == K_F32), "pre-split weight planes go with the scheduled fp32 loop");
-    constexpr int STG = W3 ? T::STAGE_F3 : T::STAGE_F;   /* floats per LDS stage */
-    Staging<T, AMODE, ES, W3> stg;
+    static_assert(NPL == 0 || (SCHED && INK == K_F32), "pre-split weight planes go with the scheduled fp32 loop");
+    constexpr int STG = T::stage_f(NPL);   /* floats per LDS stage */
+    Staging<T, AMODE, ES, NPL> stg;
     stg.init(p, m0, n0, wave, lane);
 
     f32x4 acc[IT][JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         /* fp8 operands carry scales: the sum is rescaled before the bias is added (epilogue) */
-        const f32x4 bv = FP8IN ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
-                               : *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 16 * JT + j * 16 + 4 * q);
+        f32x4 bv = FP8IN ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
+                         : *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 16 * JT + j * 16 + 4 * q);
+        if (NPL == 2)   /* fp16 weight parts carry a power-of-two scale: exact, undone in the epilogue */
+            bv = bv * p.w_scale;
 #pragma unroll
         for (int i = 0; i < IT; ++i)
             acc[i][j] = bv;
@@ -591,21 +638,10 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             ra[0][1] = *reinterpret_cast<const f32x4 *>(ab + k1);
             ra[1][0] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k0);
             ra[1][1] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k1);
-            if constexpr (W3) {
-                /* weights were split once, at context creation: three bf16 planes of 64-byte rows */
-                const float *w3 = smem + stage * STG + BM * BK + (wn * 16 * JT + l15) * 16 + 4 * (q ^ ((l15 >> 2) & 3));
 #pragma unroll
-                for (int j = 0; j < JT; ++j) {
-                    w0[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + j * 256));
-                    w1[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + BN * 16 + j * 256));
-                    w2[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + 2 * BN * 16 + j * 256));
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < JT; ++j)
-                    split8(*reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k0),
-                           *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k1), w0[j], w1[j], w2[j]);
-            }
+            for (int j = 0; j < JT; ++j)
+                split8(*reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k0),
+                       *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k1), w0[j], w1[j], w2[j]);
             split8(ra[0][0], ra[0][1], c0, c1, c2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -673,21 +709,24 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     };
 
     const int nk = p.K / KE;
-    if constexpr (W3) {
+    if constexpr (NPL != 0) {
         /* K loop pipelined across steps.  With the weights pre-split a step's only VALU work is
          * the A splits, so the barrier can sit before the LAST fragment group (by then every
          * wave has read all of tile t): behind that group's MFMAs the W fragments of tile t+1
-         * are fetched in place (W[j] is dead once its six MFMAs are issued) and A fragment 0 of
+         * are fetched in place (W[j] is dead once its MFMAs are issued) and A fragment 0 of
          * tile t+1 is split -- the next step starts on its MFMAs at once. */
         static_assert(IT >= 3, "pipeline depth");
+        typedef typename PartT<NPL>::type frag_t;
+        constexpr int NT6 = NPL == 3 ? 6 : 3;                 /* products per block */
+        constexpr int VPM = 2;                                /* split instructions per MFMA slot */
         const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
-        const int w3o = BM * BK + (wn * 16 * JT + l15) * 16 + 4 * (q ^ ((l15 >> 2) & 3));
-        bf16x8 w0[JT], w1[JT], w2[JT], c0, c1, c2;
+        const int wpo = BM * BK + (wn * 16 * JT + l15) * 16 + 4 * (q ^ ((l15 >> 2) & 3));
+        frag_t w[JT][NPL], c[NPL];
         f32x4 ra[2][2];
-        auto read_w = [&](const float *w3, int j) {
-            w0[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + j * 256));
-            w1[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + BN * 16 + j * 256));
-            w2[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(w3 + 2 * BN * 16 + j * 256));
+        auto read_w = [&](const float *base, int j) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                w[j][pl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const f32x4 *>(base + pl * BN * 16 + j * 256));
         };
         auto read_a01 = [&](const float *ab) {
             ra[0][0] = *reinterpret_cast<const f32x4 *>(ab + k0);
@@ -695,35 +734,38 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             ra[1][0] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k0);
             ra[1][1] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k1);
         };
+        auto mfma_group = [&](int i) { /* per accumulator: smallest terms first */
+#pragma unroll
+            for (int t = 0; t < NT6; ++t)
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+                    acc[i][j] = mfma_part(w[j][term_w<NPL>(t)], c[term_a<NPL>(t)], acc[i][j]);
+        };
+        auto interleave = [&]() {
+#pragma unroll
+            for (int r = 0; r < NT6 * JT - 2; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        };
         /* groups first .. IT-2: read fragment i+2, split fragment i+1, MFMAs of fragment i */
         auto front = [&](const float *ab) {
 #pragma unroll
             for (int i = 0; i < IT - 1; ++i) {
-                bf16x8 n0, n1, n2;
-                split8(ra[(i + 1) & 1][0], ra[(i + 1) & 1][1], n0, n1, n2);
+                frag_t n[NPL];
+                split_parts(ra[(i + 1) & 1][0], ra[(i + 1) & 1][1], n);
                 if (i + 2 < IT) {
                     ra[i & 1][0] = *reinterpret_cast<const f32x4 *>(ab + (i + 2) * 16 * BK + k0);
                     ra[i & 1][1] = *reinterpret_cast<const f32x4 *>(ab + (i + 2) * 16 * BK + k1);
                 }
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int j = 0; j < JT; ++j) {
-                        const bf16x8 wp = (t == 0 || t == 3 || t == 5) ? w0[j] : (t == 1) ? w2[j] : w1[j];
-                        const bf16x8 ap = (t == 0) ? c2 : (t == 2 || t == 3) ? c1 : c0;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp, ap, acc[i][j], 0, 0, 0);
-                    }
+                mfma_group(i);
                 if (i + 2 < IT)
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                interleave();
 #pragma unroll
-                for (int r = 0; r < 6 * JT - 2; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, SGB_V, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                c0 = n0;
-                c1 = n1;
-                c2 = n2;
+                for (int pl = 0; pl < NPL; ++pl)
+                    c[pl] = n[pl];
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -734,9 +776,9 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             stg.dma(p, smem, 1, 1, wave);
 #pragma unroll
         for (int j = 0; j < JT; ++j)
-            read_w(smem + w3o, j);
+            read_w(smem + wpo, j);
         read_a01(a_lane);
-        split8(ra[0][0], ra[0][1], c0, c1, c2);
+        split_parts(ra[0][0], ra[0][1], c);
         __builtin_amdgcn_sched_barrier(0);
 
         for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -745,41 +787,26 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             if (kt + 2 < nk)
                 stg.dma(p, smem, kt & 1, kt + 2, wave);
             const float *nx = smem + ((kt + 1) & 1) * STG;
-            bf16x8 n0, n1, n2;
+            frag_t n[NPL];
             read_a01(nx + (wm * 16 * IT + l15) * BK);
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                f32x4 c = acc[IT - 1][j];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], c2, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j], c0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], c1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], c1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], c0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], c0, c, 0, 0, 0);
-                acc[IT - 1][j] = c;
-                read_w(nx + w3o, j);          /* in place: W(kt)[j] is dead from here on */
-            }
-            split8(ra[0][0], ra[0][1], n0, n1, n2);
+                f32x4 cc = acc[IT - 1][j];
 #pragma unroll
-            for (int r = 0; r < 6 * JT - 2; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, SGB_V, 0);
+                for (int t = 0; t < NT6; ++t)
+                    cc = mfma_part(w[j][term_w<NPL>(t)], c[term_a<NPL>(t)], cc);
+                acc[IT - 1][j] = cc;
+                read_w(nx + wpo, j);          /* in place: W(kt)[j] is dead from here on */
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            c0 = n0;
-            c1 = n1;
-            c2 = n2;
+            split_parts(ra[0][0], ra[0][1], n);
+            interleave();
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                c[pl] = n[pl];
             __builtin_amdgcn_sched_barrier(0);
         }
         front(a_lane + ((nk - 1) & 1) * STG);
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                const bf16x8 wp = (t == 0 || t == 3 || t == 5) ? w0[j] : (t == 1) ? w2[j] : w1[j];
-                const bf16x8 ap = (t == 0) ? c2 : (t == 2 || t == 3) ? c1 : c0;
-                acc[IT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp, ap, acc[IT - 1][j], 0, 0, 0);
-            }
+        mfma_group(IT - 1);
     } else {
         stg.dma(p, smem, 0, 0, wave);
         __syncthreads();
@@ -809,6 +836,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
         for (int j = 0; j < JT; ++j) {
             const int col = n0 + wn * 16 * JT + j * 16 + 4 * q;
             f32x4 v = acc[i][j];
+            if (NPL == 2)
+                v = v * p.inv_w_scale;
             if (FP8IN) /* undo the operand scales (per tensor for A, per output column for W), then the bias */
                 v = v * *reinterpret_cast<const f32x4 *>(p.col_scale + col) + *reinterpret_cast<const f32x4 *>(p.bias + col);
             if (EPI == EPI_GELU) {
@@ -833,19 +862,19 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     }
 }
 
-template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false, bool W3 = false>
+template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false, int NPL = 0>
 int launch_mf16(hipStream_t st, GemmParams p)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, W3>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W3 ? T::LDS3 : T::LDS)));
+        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, NPL>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::lds(NPL)));
         attr_set = true;
     }
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = p.N / T::BN;
-    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, W3>), dim3(p.mtiles * p.ntiles),
-                       dim3(T::NT), W3 ? T::LDS3 : T::LDS, st, p);
+    hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, NPL>), dim3(p.mtiles * p.ntiles),
+                       dim3(T::NT), T::lds(NPL), st, p);
     VH_LAUNCH_CHECK("gemm_mf16_kernel");
     return 0;
 }
@@ -1193,6 +1222,69 @@ extern "C" int vh_launch_split3_planes(vh_stream_t s, const float *weight, void 
     return 0;
 }
 
+namespace {
+
+/* fp32 [N][K] -> two fp16 planes of w*scale, [K/32][2][N][32] (K step, part, row, element). */
+__global__ void split2h_planes_kernel(const float *__restrict__ in, _Float16 *__restrict__ out, int N, int K, float scale)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * K)
+        return;
+    const int n = (int)(i / K), k = (int)(i - (size_t)n * K);
+    const float x = in[i] * scale;
+    const _Float16 h = (_Float16)x;
+    const size_t o = (((size_t)(k >> 5) * 2) * N + n) * 32 + (k & 31);
+    out[o] = h;
+    out[o + (size_t)N * 32] = (_Float16)(x - (float)h);
+}
+
+} // namespace
+
+extern "C" int vh_launch_split2h_planes(vh_stream_t s, const float *weight, void *planes, int rows, int cols, float scale)
+{
+    if (!weight || !planes || rows <= 0 || cols <= 0 || cols % BK != 0 || !(scale > 0.0f))
+        return vh_fail(1, "vh_launch_split2h_planes: bad argument (cols must be a multiple of %d, scale > 0)", BK);
+    const size_t count = (size_t)rows * cols;
+    hipLaunchKernelGGL(split2h_planes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)s, weight,
+                       static_cast<_Float16 *>(planes), rows, cols, scale);
+    VH_LAUNCH_CHECK("split2h_planes_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_linear_h2(vh_stream_t s, float *output, const void *weight_planes, float weight_scale,
+                                   const float *input, const float *bias, int rowA, int colA, int colB, int doGelu,
+                                   const float *residual)
+{
+    if (!output || !weight_planes || !input || !bias)
+        return vh_fail(1, "vh_launch_linear_h2: null pointer argument");
+    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % BK != 0 || colB % 128 != 0 || !(weight_scale > 0.0f))
+        return vh_fail(1, "vh_launch_linear_h2: needs colA %% 32 == 0, colB %% 128 == 0, scale > 0 (%d,%d,%d)", rowA, colA, colB);
+    if (doGelu && residual)
+        return vh_fail(1, "vh_launch_linear_h2: GELU and residual together are not a model op");
+    GemmParams p = {};
+    p.A = input; p.W = weight_planes; p.bias = bias; p.R = residual; p.C = output;
+    p.M = rowA; p.N = colB; p.K = colA;
+    p.w_scale = weight_scale; p.inv_w_scale = 1.0f / weight_scale;
+    if (!aligned16(p) || (((uintptr_t)weight_planes | (uintptr_t)input) & 15) != 0)
+        return vh_fail(1, "vh_launch_linear_h2: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)s;
+    int c = cfg_override();
+    const bool resid_short_k = residual && colA < 2048;
+    if (c != 1 && c != 3)
+        c = (colB % 256 == 0 && rowA >= 4096 && !resid_short_k) ? 3 : 1;
+    if (c == 3 && colB % 256 != 0)
+        c = 1;
+#define VH_H2(EPI)                                                                     \
+    (c == 3 ? launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, 2>(st, p)            \
+            : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, 2>(st, p))
+    if (doGelu)
+        return VH_H2(EPI_GELU);
+    if (residual)
+        return VH_H2(EPI_RESID);
+    return VH_H2(EPI_NONE);
+#undef VH_H2
+}
+
 extern "C" int vh_launch_linear_w3(vh_stream_t s, float *output, const void *weight_planes, const float *input,
                                    const float *bias, int rowA, int colA, int colB, int doGelu, const float *residual)
 {
@@ -1215,8 +1307,8 @@ extern "C" int vh_launch_linear_w3(vh_stream_t s, float *output, const void *wei
     if (c == 3 && colB % 256 != 0)
         c = 1;
 #define VH_W3(EPI)                                                                        \
-    (c == 3 ? launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, true>(st, p)            \
-            : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, true>(st, p))
+    (c == 3 ? launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, 3>(st, p)            \
+            : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, 3>(st, p))
     if (doGelu)
         return VH_W3(EPI_GELU);
     if (residual)

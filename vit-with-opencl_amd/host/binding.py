@@ -36,6 +36,7 @@ EXPORTS = [
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_profile_select", "vit_hip_create_ex", "vit_hip_precision",
     "vh_launch_convert_bf16", "vh_launch_layer_norm_bf16", "vh_launch_linear_bf16", "vh_launch_attention_bf16",
     "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_launch_split3_planes", "vh_launch_linear_w3",
+    "vh_launch_split2h_planes", "vh_launch_linear_h2",
     "vh_launch_convert_fp8", "vh_launch_quantize_rows_fp8", "vh_launch_absmax", "vh_launch_scale_vector",
     "vh_launch_layer_norm_fp8", "vh_launch_linear_fp8", "vit_hip_calibrate_fp8", "vit_hip_fp8_scales",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
@@ -140,6 +141,8 @@ def lib() -> C.CDLL:
     L.vh_launch_attention.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_split3_planes.argtypes = [voidp, voidp, voidp, i, i]
     L.vh_launch_linear_w3.argtypes = [voidp] + [voidp] * 4 + [i, i, i, i, voidp]
+    L.vh_launch_split2h_planes.argtypes = [voidp, voidp, voidp, i, i, C.c_float]
+    L.vh_launch_linear_h2.argtypes = [voidp, voidp, voidp, C.c_float, voidp, voidp, i, i, i, i, voidp]
     L.vh_launch_softmax.argtypes = [voidp, voidp, voidp, i, i]
     L.vit_config_preset.argtypes = [C.POINTER(VitConfig), C.c_char_p]
     L.vit_config_tokens.argtypes = [C.POINTER(VitConfig)]
@@ -297,7 +300,7 @@ class ViTHip:
         self.ctx = voidp()
         self.precision = precision
         rc = self.L.vit_hip_create_ex(C.byref(self.ctx), C.byref(cfg), networks(weights), len(weights),
-                                      device, max_batch, {"f32": 0, "bf16": 1, "fp8": 2}[precision])
+                                      device, max_batch, {"f32": 0, "bf16": 1, "fp8": 2, "f32_fp16x2": 3}[precision])
         check(rc, "vit_hip_create_ex")
         self.max_batch = max_batch
         self.tokens = tokens(cfg)
