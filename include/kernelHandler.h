@@ -141,6 +141,8 @@ int vh_launch_split2h_planes(vh_stream_t s, const float *weight, void *planes, i
 int vh_launch_linear_h2(vh_stream_t s, float *output, const void *weight_planes, float weight_scale,
                         const float *input, const float *bias, int rowA, int colA, int colB,
                         int doGelu, const float *residual);
+int vh_launch_attention_h2(vh_stream_t s, const float *qkv, float *output, int n_images, int tokens,
+                           int embed_dim, int num_heads);   /* Q.K^T and P.V likewise */
 
 /* Scaled-dot-product attention over the fused QKV rows produced by
  * vh_launch_linear (row = Q[embed] | K[embed] | V[embed]); per (image, head):

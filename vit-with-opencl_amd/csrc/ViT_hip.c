@@ -459,7 +459,7 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         const float *ws = ctx->w3_scale + 4 + 12 * l;
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
         OP(VIT_OP_QKV, vh_launch_linear_h2(s, ctx->qkv, l3[2], ws[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
-        OP(VIT_OP_ATTENTION, vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+        OP(VIT_OP_ATTENTION, vh_launch_attention_h2(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
         OP(VIT_OP_OUT_PROJ, vh_launch_linear_h2(s, ctx->x, l3[4], ws[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
         OP(VIT_OP_FC1, vh_launch_linear_h2(s, ctx->hid, l3[8], ws[8], ctx->y, lw[9], rows, E, F, 1, NULL));

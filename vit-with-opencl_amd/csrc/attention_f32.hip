@@ -36,6 +36,7 @@
  */
 #include "kernelHandler.h"
 #include "vit_kernels.h"
+#include "fp32_split.h"
 
 #include <cstdlib>
 
@@ -48,7 +49,12 @@ constexpr int MAX_ROWS = (MAX_LDS - 64) / (3 * HD * 4) / 8 * 8; /* rows per buff
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int NKT, bool OUTBF16> /* NKT 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT */
+/* NPL: how the two fp32 products Q.K^T and P.V reach the matrix cores.  0: v_mfma_f32_32x32x2_f32
+ * (fp32 operands, 1/16 of the 16-bit rate).  3: every operand fragment split exactly into three
+ * bf16 parts in registers, six v_mfma_f32_32x32x16_bf16 per block (the GEMMs' SPLIT3, same
+ * accuracy, 2.67x the fp32 MFMA rate -- the kernel turns from MFMA-bound to VALU-bound).
+ * 2: two fp16 parts, three products (the opt-in emulation mode, fp32_split.h). */
+template <int NKT, bool OUTBF16, int NPL> /* NKT 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT */
 __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__restrict__ qkv,
                                                                 void *__restrict__ out, int T,
                                                                 int E, int H, int n_items, int RB)
@@ -93,10 +99,19 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
     f32x4 qf[HD / 8];
     auto load_q = [&](int it) {
         const int b = it / H, h = it - b * H;
-        const float *row = qkv + ((size_t)b * T + qc) * ld + (size_t)h * HD + 4 * lh;
+        if (NPL == 0) {
+            const float *row = qkv + ((size_t)b * T + qc) * ld + (size_t)h * HD + 4 * lh;
 #pragma unroll
-        for (int c = 0; c < HD / 8; ++c)
-            qf[c] = *reinterpret_cast<const f32x4 *>(row + 8 * c);
+            for (int c = 0; c < HD / 8; ++c)
+                qf[c] = *reinterpret_cast<const f32x4 *>(row + 8 * c);
+        } else { /* 16-deep MFMA groups: lane half lh holds d = 16g + 8lh .. +7 in qf[2g], qf[2g+1] */
+            const float *row = qkv + ((size_t)b * T + qc) * ld + (size_t)h * HD + 8 * lh;
+#pragma unroll
+            for (int g = 0; g < HD / 16; ++g) {
+                qf[2 * g] = *reinterpret_cast<const f32x4 *>(row + 16 * g);
+                qf[2 * g + 1] = *reinterpret_cast<const f32x4 *>(row + 16 * g + 4);
+            }
+        }
     };
 
     /* Per-lane LDS byte offsets (item-independent).  K fragment of key row r, d chunk
@@ -107,8 +122,10 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
         const int rl = min(32 * (NKT - 1) + lr, RB - 1);
 #pragma unroll
         for (int c = 0; c < HD / 8; ++c) {
-            kofs[c] = lr * (HD * 4) + 16 * ((2 * c + lh) ^ (lr & 15));
-            kofs_last[c] = rl * (HD * 4) + 16 * ((2 * c + lh) ^ (rl & 15));
+            /* NPL == 0: chunk 2c + lh (d = 8c + 4lh ..); split forms: chunk 4g + 2lh + hh for c = 2g + hh */
+            const int chunk = NPL == 0 ? 2 * c + lh : 4 * (c >> 1) + 2 * lh + (c & 1);
+            kofs[c] = lr * (HD * 4) + 16 * (chunk ^ (lr & 15));
+            kofs_last[c] = rl * (HD * 4) + 16 * (chunk ^ (rl & 15));
         }
     }
     const int vofs = (4 * lh * HD + lr) * 4;
@@ -156,6 +173,14 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
                 __builtin_amdgcn_s_sleep(32);
         }
 
+        /* split forms: this item's query fragments into parts, once (qf is free for the next item's loads) */
+        typename PartT<NPL>::type qp[NPL == 0 ? 1 : HD / 16][NPL == 0 ? 1 : NPL];
+        if constexpr (NPL != 0) {
+#pragma unroll
+            for (int g = 0; g < HD / 16; ++g)
+                split_parts(qf[2 * g], qf[2 * g + 1], qp[g]);
+        }
+
         /* S^T tiles: rows = keys of tile j, column = this lane's query. */
         f32x16 s[NKT];
 #pragma unroll
@@ -163,16 +188,29 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 s[j][r] = 0.0f;
+            /* rows 32j + lr: lane offset + compile-time j*8 KiB; only the last tile can
+             * run past the buffer and uses the clamped-row offsets */
+            auto kfrag = [&](int c) {
+                return (j < NKT - 1) ? *reinterpret_cast<const f32x4 *>(Kb + kofs[c] + j * 32 * HD * 4)
+                                     : *reinterpret_cast<const f32x4 *>(Kb + kofs_last[c]);
+            };
+            if constexpr (NPL == 0) {
 #pragma unroll
-            for (int c = 0; c < HD / 8; ++c) {
-                /* rows 32j + lr: lane offset + compile-time j*8 KiB; only the last tile can
-                 * run past the buffer and uses the clamped-row offsets */
-                const f32x4 kf = (j < NKT - 1)
-                    ? *reinterpret_cast<const f32x4 *>(Kb + kofs[c] + j * 32 * HD * 4)
-                    : *reinterpret_cast<const f32x4 *>(Kb + kofs_last[c]);
+                for (int c = 0; c < HD / 8; ++c) {
+                    const f32x4 kf = kfrag(c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[j], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)
+                        s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < HD / 16; ++g) {
+                    typename PartT<NPL>::type kp[NPL];
+                    split_parts(kfrag(2 * g), kfrag(2 * g + 1), kp);
+#pragma unroll
+                    for (int t = 0; t < (NPL == 3 ? 6 : 3); ++t)
+                        s[j] = mfma_part(kp[term_w<NPL>(t)], qp[g][term_a<NPL>(t)], s[j]);
+                }
             }
             if (!late) {
                 for (int p = wave + NKT * j; p < pieces; p += NKT * NKT) {
@@ -243,23 +281,54 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
             o[0][r] = 0.0f;
             o[1][r] = 0.0f;
         }
-#pragma unroll
-        for (int j = 0; j < NKT; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (j == NKT - 1 && 32 * j + 8 * g >= T)
-                    continue;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int r = 4 * g + rr;
-                    /* keys k0 + rr + 4*lh with k0 = 32j + 8g < T: all 8 rows exist (RB = T up to 8) */
-                    const char *vp = Vb + vofs + (32 * j + 8 * g + rr) * (HD * 4);
-                    const float v0 = *reinterpret_cast<const float *>(vp);
-                    const float v1 = *reinterpret_cast<const float *>(vp + 32 * 4);
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[j][r], o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[j][r], o[1], 0, 0, 0);
+        if constexpr (NPL == 0) {
+    #pragma unroll
+            for (int j = 0; j < NKT; ++j)
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (j == NKT - 1 && 32 * j + 8 * g >= T)
+                        continue;
+    #pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = 4 * g + rr;
+                        /* keys k0 + rr + 4*lh with k0 = 32j + 8g < T: all 8 rows exist (RB = T up to 8) */
+                        const char *vp = Vb + vofs + (32 * j + 8 * g + rr) * (HD * 4);
+                        const float v0 = *reinterpret_cast<const float *>(vp);
+                        const float v1 = *reinterpret_cast<const float *>(vp + 32 * 4);
+                        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[j][r], o[0], 0, 0, 0);
+                        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[j][r], o[1], 0, 0, 0);
+                    }
                 }
-            }
+        } else {
+            /* 16 keys per MFMA: contraction slot (lh, e) is key 32j + 16t + (e & 3) + 8*(e >> 2) + 4*lh
+             * -- the key whose probability accumulator register 8t + e of tile j already holds. */
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (j == NKT - 1 && 32 * j + 16 * t >= T)
+                        continue;
+                    typename PartT<NPL>::type pp[NPL];
+                    split_parts(f32x4{s[j][8 * t], s[j][8 * t + 1], s[j][8 * t + 2], s[j][8 * t + 3]},
+                                f32x4{s[j][8 * t + 4], s[j][8 * t + 5], s[j][8 * t + 6], s[j][8 * t + 7]}, pp);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        /* rows 32j + 16t + 4lh + {0..3, 8..11} exist: RB is T rounded up to 16 */
+                        const char *vp = Vb + vofs + (32 * j + 16 * t) * (HD * 4) + dt * 32 * 4;
+                        f32x4 vlo, vhi;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            vlo[e] = *reinterpret_cast<const float *>(vp + e * (HD * 4));
+                            vhi[e] = *reinterpret_cast<const float *>(vp + (8 + e) * (HD * 4));
+                        }
+                        typename PartT<NPL>::type vq[NPL];
+                        split_parts(vlo, vhi, vq);
+#pragma unroll
+                        for (int tt = 0; tt < (NPL == 3 ? 6 : 3); ++tt)
+                            o[dt] = mfma_part(vq[term_w<NPL>(tt)], pp[term_a<NPL>(tt)], o[dt]);
+                    }
+                }
+        }
 
         if (next < n_items) {
             asm volatile("" ::: "memory"); /* not above the P.V reads: P's registers must be dead */
@@ -289,14 +358,15 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
     }
 }
 
-template <int NKT, bool OUTBF16>
+template <int NKT, bool OUTBF16, int NPL>
 int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, int E, int H)
 {
-    const int RB = (T + 7) / 8 * 8; /* rows per buffer: whole 8-key register groups, whole 4-row DMA pieces */
+    /* rows per buffer: whole register groups of keys (8 for the fp32 MFMA, 16 for the split forms), whole 4-row DMA pieces */
+    const int RB = NPL == 0 ? (T + 7) / 8 * 8 : (T + 15) / 16 * 16;
     const size_t lds = sizeof(float) * 3 * RB * HD + 64;
     static bool attr_set = false;
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)attention_f32_kernel<NKT, OUTBF16>,
+        VH_TRY(hipFuncSetAttribute((const void *)attention_f32_kernel<NKT, OUTBF16, NPL>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         attr_set = true;
     }
@@ -310,22 +380,28 @@ int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, i
     }
     const int n_items = n_images * H;
     const int grid = n_items < num_cus ? n_items : num_cus;
-    hipLaunchKernelGGL((attention_f32_kernel<NKT, OUTBF16>), dim3(grid), dim3(64 * NKT), lds, st, qkv, out,
+    hipLaunchKernelGGL((attention_f32_kernel<NKT, OUTBF16, NPL>), dim3(grid), dim3(64 * NKT), lds, st, qkv, out,
                        T, E, H, n_items, RB);
     VH_LAUNCH_CHECK("attention_f32_kernel");
     return 0;
 }
 
+/* arith: 0 = fp32 MFMA, 3 = exact three-part bf16 split (default), 2 = two fp16 parts (emulation mode) */
 template <int NKT>
-int launch(hipStream_t st, const float *qkv, void *out, int out_bf16, int n_images, int T, int E, int H)
+int launch(hipStream_t st, const float *qkv, void *out, int out_bf16, int arith, int n_images, int T, int E, int H)
 {
-    return out_bf16 ? launch_k<NKT, true>(st, qkv, out, n_images, T, E, H)
-                    : launch_k<NKT, false>(st, qkv, out, n_images, T, E, H);
+    if (arith == 2 && !out_bf16)
+        return launch_k<NKT, false, 2>(st, qkv, out, n_images, T, E, H);
+    if (arith == 0)
+        return out_bf16 ? launch_k<NKT, true, 0>(st, qkv, out, n_images, T, E, H)
+                        : launch_k<NKT, false, 0>(st, qkv, out, n_images, T, E, H);
+    return out_bf16 ? launch_k<NKT, true, 3>(st, qkv, out, n_images, T, E, H)
+                    : launch_k<NKT, false, 3>(st, qkv, out, n_images, T, E, H);
 }
 
 } // namespace
 
-static int launch_attention(vh_stream_t s, const float *qkv, void *output, int out_bf16, int n_images,
+static int launch_attention(vh_stream_t s, const float *qkv, void *output, int out_bf16, int arith, int n_images,
                             int tokens, int embed_dim, int num_heads)
 {
     if (!qkv || !output)
@@ -342,26 +418,41 @@ static int launch_attention(vh_stream_t s, const float *qkv, void *output, int o
     }
     if (embed_dim != num_heads * HD || tokens > MAX_ROWS || force_tiled)
         return vh_attention_tiled(s, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    static int native = -1;
+    if (native < 0) {
+        const char *env = getenv("VIT_HIP_ATTN_MFMA");   /* "fp32": the fp32 matrix instruction */
+        native = (env && env[0] == 'f') ? 1 : 0;
+    }
+    if (native && arith == 3)
+        arith = 0;
     hipStream_t st = (hipStream_t)s;
     switch ((tokens + 31) / 32) {
-    case 1: return launch<1>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
-    case 2: return launch<2>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
-    case 3: return launch<3>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
-    case 4: return launch<4>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
-    case 5: return launch<5>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
-    case 6: return launch<6>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
-    default: return launch<7>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    case 1: return launch<1>(st, qkv, output, out_bf16, arith, n_images, tokens, embed_dim, num_heads);
+    case 2: return launch<2>(st, qkv, output, out_bf16, arith, n_images, tokens, embed_dim, num_heads);
+    case 3: return launch<3>(st, qkv, output, out_bf16, arith, n_images, tokens, embed_dim, num_heads);
+    case 4: return launch<4>(st, qkv, output, out_bf16, arith, n_images, tokens, embed_dim, num_heads);
+    case 5: return launch<5>(st, qkv, output, out_bf16, arith, n_images, tokens, embed_dim, num_heads);
+    case 6: return launch<6>(st, qkv, output, out_bf16, arith, n_images, tokens, embed_dim, num_heads);
+    default: return launch<7>(st, qkv, output, out_bf16, arith, n_images, tokens, embed_dim, num_heads);
     }
 }
 
 extern "C" int vh_launch_attention(vh_stream_t s, const float *qkv, float *output, int n_images,
                                    int tokens, int embed_dim, int num_heads)
 {
-    return launch_attention(s, qkv, output, 0, n_images, tokens, embed_dim, num_heads);
+    return launch_attention(s, qkv, output, 0, 3, n_images, tokens, embed_dim, num_heads);
 }
 
 extern "C" int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *output, int n_images,
                                         int tokens, int embed_dim, int num_heads)
 {
-    return launch_attention(s, qkv, output, 1, n_images, tokens, embed_dim, num_heads);
+    return launch_attention(s, qkv, output, 1, 3, n_images, tokens, embed_dim, num_heads);
+}
+
+/* The emulation mode's attention: Q.K^T and P.V on two fp16 parts / three products (kernelHandler.h,
+ * vh_launch_linear_h2); shapes outside the resident-K/V kernel use the streaming fp32 kernel. */
+extern "C" int vh_launch_attention_h2(vh_stream_t s, const float *qkv, float *output, int n_images,
+                                      int tokens, int embed_dim, int num_heads)
+{
+    return launch_attention(s, qkv, output, 0, 2, n_images, tokens, embed_dim, num_heads);
 }
