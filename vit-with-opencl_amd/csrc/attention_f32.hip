@@ -44,6 +44,9 @@ namespace {
 
 constexpr int HD = 64;                    /* head dim this kernel is specialised for */
 constexpr int MAX_LDS = 160 * 1024;
+#ifndef LATE_SCALE
+#define LATE_SCALE 100   /* per cent of the default hold-back of a SIMD's second wave (tuning) */
+#endif
 constexpr int MAX_ROWS = (MAX_LDS - 64) / (3 * HD * 4) / 8 * 8; /* rows per buffer with 3 buffers: 208 */
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -158,6 +161,9 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
          * the previous item.  The second wave of each SIMD issues its share at once (it
          * is about to be held back anyway); the first waves interleave theirs with the
          * QK^T tiles so that issuing ~15 DMA instructions does not delay their MFMAs. */
+        /* hold-back of a SIMD's second wave ~ one Q.K^T phase of the first: 64 cycles per key with the
+         * fp32 MFMA, about a third of that on the split forms */
+        constexpr int LATE_CYCLES_PER_KEY = (NPL == 0 ? 64 : NPL == 3 ? 24 : 14) * LATE_SCALE / 100;
         const bool late = NKT > 4 && wave >= 4;
         const float *v_src = head_base(item, 2);
         const float *k_src = head_base(next < n_items ? next : item, 1);
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_fetch_add(v_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)(NKT * 32 * 64))
+            while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)(NKT * 32 * LATE_CYCLES_PER_KEY))
                 __builtin_amdgcn_s_sleep(32);
         }
 
