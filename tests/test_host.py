@@ -232,3 +232,17 @@ def test_result_file_and_strict_comparison(pkg, tmp_path):
     assert 0.9 < rep.top5_overlap <= 1.0
     got[0, 3] = np.nan
     assert L.vit_compare_rows(b.fptr(got), b.fptr(want), 6, 1000, 3e-4, C.byref(rep)) == 0 and rep.nonfinite == 1
+
+
+def test_public_headers_are_plain_c_and_cxx(tmp_path):
+    """The boundary is a C ABI: every public header compiles on its own as C11 (the reference's
+    Main.c is C) and as C++ (extern "C" guards), with warnings as errors."""
+    import subprocess
+    root = Path(__file__).resolve().parent.parent
+    for hdr in ("Network.h", "ViT_opencl.h", "kernelHandler.h"):
+        for lang, std, cc in (("c", "-std=c11", "gcc"), ("c++", "-std=c++17", "g++")):
+            src = tmp_path / f"t.{'c' if lang == 'c' else 'cpp'}"
+            src.write_text(f'#include "{hdr}"\nint main(void) {{ return 0; }}\n')
+            r = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", f"-I{root / 'include'}", str(src)],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, f"{hdr} as {lang}: {r.stderr[-800:]}"
