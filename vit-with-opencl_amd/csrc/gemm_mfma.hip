@@ -1147,6 +1147,48 @@ __global__ void split3_planes_kernel(const float *__restrict__ in, __bf16 *__res
 
 } // namespace
 
+namespace {
+
+/* Pre-split-weight GEMM on the tile the shape wants, with the last, partly filled scheduling round
+ * of 256x256 tiles handed to 128x128 tiles instead (VIT_HIP_GEMM_TAIL=0 disables): with one
+ * workgroup per CU a grid of r.f rounds costs ceil(r.f) rounds; the remainder rows as quarter-size
+ * tiles cost about f/2. */
+template <int EPI, int NPL>
+int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
+{
+    int c = cfg_override();
+    if (c != 1 && c != 3)
+        c = (p.N % 256 == 0 && p.M >= 4096 && !prefer_small) ? 3 : 1;
+    if (c == 3 && p.N % 256 != 0)
+        c = 1;
+    if (c != 3)
+        return launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
+    static int num_cus = 0, tail = -1;
+    if (num_cus == 0) {
+        int dev = 0;
+        VH_TRY(hipGetDevice(&dev));
+        VH_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const char *env = getenv("VIT_HIP_GEMM_TAIL");
+        tail = (env && env[0] == '0') ? 0 : 1;
+    }
+    const int ntiles = p.N / 256, mtiles = (p.M + 255) / 256;
+    const long tiles = (long)mtiles * ntiles, full = tiles / num_cus, rem = tiles % num_cus;
+    const int rows_big = (int)(full * num_cus / ntiles) * 256;
+    if (!tail || full < 1 || rem == 0 || 4 * rem > 3 * num_cus || rows_big <= 0 || rows_big >= p.M)
+        return launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
+    GemmParams big = p, rest = p;
+    big.M = rows_big;
+    rest.M = p.M - rows_big;
+    rest.A = static_cast<const float *>(p.A) + (size_t)rows_big * p.K;
+    rest.C = static_cast<float *>(p.C) + (size_t)rows_big * p.N;
+    if (p.R)
+        rest.R = p.R + (size_t)rows_big * p.N;
+    const int rc = launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big);
+    return rc ? rc : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, rest);
+}
+
+} // namespace
+
 extern "C" int vh_launch_split3_planes(vh_stream_t s, const float *weight, void *planes, int rows, int cols)
 {
     if (!weight || !planes || rows <= 0 || cols <= 0 || cols % BK != 0)
@@ -1204,21 +1246,12 @@ extern "C" int vh_launch_linear_h2(vh_stream_t s, float *output, const void *wei
     if (!aligned16(p) || (((uintptr_t)weight_planes | (uintptr_t)input) & 15) != 0)
         return vh_fail(1, "vh_launch_linear_h2: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)s;
-    int c = cfg_override();
-    const bool resid_short_k = residual && colA < 2048;
-    if (c != 1 && c != 3)
-        c = (colB % 256 == 0 && rowA >= 4096 && !resid_short_k) ? 3 : 1;
-    if (c == 3 && colB % 256 != 0)
-        c = 1;
-#define VH_H2(EPI)                                                                     \
-    (c == 3 ? launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, 2>(st, p)            \
-            : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, 2>(st, p))
+    const bool prefer_small = residual && colA < 2048;
     if (doGelu)
-        return VH_H2(EPI_GELU);
+        return launch_planes<EPI_GELU, 2>(st, p, prefer_small);
     if (residual)
-        return VH_H2(EPI_RESID);
-    return VH_H2(EPI_NONE);
-#undef VH_H2
+        return launch_planes<EPI_RESID, 2>(st, p, prefer_small);
+    return launch_planes<EPI_NONE, 2>(st, p, prefer_small);
 }
 
 extern "C" int vh_launch_linear_w3(vh_stream_t s, float *output, const void *weight_planes, const float *input,
@@ -1236,21 +1269,12 @@ extern "C" int vh_launch_linear_w3(vh_stream_t s, float *output, const void *wei
     if (!aligned16(p) || (((uintptr_t)weight_planes | (uintptr_t)input) & 15) != 0)
         return vh_fail(1, "vh_launch_linear_w3: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)s;
-    int c = cfg_override();
-    const bool resid_short_k = residual && colA < 2048;
-    if (c != 1 && c != 3)
-        c = (colB % 256 == 0 && rowA >= 4096 && !resid_short_k) ? 3 : 1;
-    if (c == 3 && colB % 256 != 0)
-        c = 1;
-#define VH_W3(EPI)                                                                        \
-    (c == 3 ? launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, 3>(st, p)            \
-            : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, 3>(st, p))
+    const bool prefer_small = residual && colA < 2048;   /* measured: the N = 768, K = 768 out-projection */
     if (doGelu)
-        return VH_W3(EPI_GELU);
+        return launch_planes<EPI_GELU, 3>(st, p, prefer_small);
     if (residual)
-        return VH_W3(EPI_RESID);
-    return VH_W3(EPI_NONE);
-#undef VH_W3
+        return launch_planes<EPI_RESID, 3>(st, p, prefer_small);
+    return launch_planes<EPI_NONE, 3>(st, p, prefer_small);
 }
 
 extern "C" int vh_launch_convert_fp8(vh_stream_t s, const float *input, void *output, size_t count, float multiplier)
