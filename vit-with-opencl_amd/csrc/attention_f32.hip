@@ -18,10 +18,15 @@
  *    (16 different keys, same d chunk) would hit one slot; chunk c of row r is kept
  *    at c ^ (r & 15) instead (applied to the DMA source address and to the reads).
  *    V is read 32 consecutive floats per half-wave: conflict-free as is.
- *  - S^T = K Q^T on v_mfma_f32_32x32x2_f32: with the key index on the MFMA row and
+ *  - S^T = K Q^T on the matrix cores: with the key index on the MFMA row and
  *    the query on the lane, each lane ends up holding, for ITS query (lane & 31),
  *    all keys of its half (lane >> 5) in registers: the row softmax is register-local
  *    plus one lane-half exchange.
+ *  - Both products are fp32 products; by default they run like the GEMMs' (gemm_mfma.hip):
+ *    every operand fragment is split exactly into three bf16 parts in registers and the
+ *    six partial products of weight >= 2^-16 go through v_mfma_f32_32x32x16_bf16 (template
+ *    NPL = 3) -- the same accuracy as v_mfma_f32_32x32x2_f32 (NPL = 0, VIT_HIP_ATTN_MFMA=fp32)
+ *    at 2.67x its rate, which turns the kernel from MFMA-bound to VALU-bound.
  *  - The normalised P never leaves registers: an S^T accumulator register is exactly
  *    the B operand (k = key pair {klo, klo+4}, column = query) of the next product
  *    O^T = V^T P^T, whose A operand V[key][d] is read from LDS with the lane on d.
