@@ -320,6 +320,24 @@ def test_model_batch_position_independence(pkg, model):
     assert np.isfinite(probs).all()
 
 
+def test_nonfinite_pixel_poisons_only_its_own_image(pkg, model, golden_full):
+    """The reference carried a NaN probe (findNaN, ViT_opencl.c:1050-1061, all calls commented
+    out).  Here: a NaN pixel makes that image's outputs NaN -- no hang, no fault -- and leaves the
+    other images of the batch bit-identical (nothing crosses images, ViT_opencl.c:926)."""
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 0, 3)
+    clean, _ = model.forward(imgs)
+    imgs[1, 1, 100, 57] = np.nan
+    logits, probs = model.forward(imgs)
+    assert np.isnan(logits[1]).all() and np.isnan(probs[1]).all()
+    assert np.array_equal(logits[0], clean[0]) and np.array_equal(logits[2], clean[2])
+    rep = pkg.binding.CompareReport()
+    import ctypes as C
+    assert pkg.lib().vit_compare_rows(pkg.binding.fptr(np.ascontiguousarray(logits)),
+                                      pkg.binding.fptr(np.ascontiguousarray(clean)), 3, 1000, 1e-4, C.byref(rep)) == 0
+    assert rep.nonfinite == 1000 and rep.max_abs_diff == 0.0
+
+
 def test_forward_rejects_empty_and_malformed_batches(pkg, model):
     """Edge cases at the boundary: n = 0, n beyond the arena, images of the wrong shape.
     Errors are status codes, never crashes, and the context stays usable."""
