@@ -645,7 +645,122 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     };
 
     const int nk = p.K / KE;
-    if constexpr (NPL != 0) {
+    if constexpr (NPL != 0 && (IT < JT)) {
+        /* Wave tile wider along N than along M (e.g. 64 x 128): with the weights pre-split only the A
+         * fragments cost VALU work, and a wave with FEWER A fragments repeats less of it (an A fragment
+         * is split by every wave of its tile row).  All IT A fragments stay resident as parts; W is
+         * taken in NC chunks of JC fragments:
+         *   chunk 0:    group i = MFMAs(A_i, W chunk 0) || split A_{i+1}; its last group refills W in
+         *               place with chunk 1 -- after chunk 0 every A read of tile t is done
+         *   chunks >= 1: group i = MFMAs(A_i, W chunk c), no VALU of their own; the last group of each
+         *               refills W in place with the next chunk
+         *   barrier before the last chunk's last group (every LDS read of tile t is done by then;
+         *   tile t+1 has landed), DMA of tile t+2; under the last chunk the next tile's A_0 is read
+         *   and split into A_0's registers (dead after that chunk's group 0). */
+        constexpr int JC = NPL == 3 ? 2 : 4, NC = JT / JC;
+        static_assert(IT >= 3 && JT % JC == 0 && NC >= 2, "W chunks");
+        typedef typename PartT<NPL>::type frag_t;
+        constexpr int NT6 = NPL == 3 ? 6 : 3;
+        const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
+        const int wpo = BM * BK + (wn * 16 * JT + l15) * 16 + 4 * (q ^ ((l15 >> 2) & 3));
+        const int apo = (wm * 16 * IT + l15) * BK;
+        frag_t w[JC][NPL], a[IT][NPL];
+        f32x4 ra[2];
+        auto read_w = [&](const float *base, int chunk, int j) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                w[j][pl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const f32x4 *>(base + pl * BN * 16 + (chunk * JC + j) * 256));
+        };
+        auto read_a = [&](const float *ab, int i) {
+            ra[0] = *reinterpret_cast<const f32x4 *>(ab + i * 16 * BK + k0);
+            ra[1] = *reinterpret_cast<const f32x4 *>(ab + i * 16 * BK + k1);
+        };
+        auto mfma_group = [&](int i, int chunk) { /* per accumulator: smallest terms first */
+#pragma unroll
+            for (int t = 0; t < NT6; ++t)
+#pragma unroll
+                for (int j = 0; j < JC; ++j)
+                    acc[i][chunk * JC + j] = mfma_part(w[j][term_w<NPL>(t)], a[i][term_a<NPL>(t)], acc[i][chunk * JC + j]);
+        };
+        auto last_group_refill = [&](int chunk, const float *wnext, int next_chunk, bool refill) {
+#pragma unroll
+            for (int j = 0; j < JC; ++j) {
+                f32x4 cc = acc[IT - 1][chunk * JC + j];
+#pragma unroll
+                for (int t = 0; t < NT6; ++t)
+                    cc = mfma_part(w[j][term_w<NPL>(t)], a[IT - 1][term_a<NPL>(t)], cc);
+                acc[IT - 1][chunk * JC + j] = cc;
+                if (refill)
+                    read_w(wnext, next_chunk, j);   /* in place: this W fragment is dead from here on */
+            }
+        };
+        auto interleave = [&]() {
+#pragma unroll
+            for (int r = 0; r < NT6 * JC - 2; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NPL == 3 ? 4 : 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        };
+
+        stg.dma(p, smem, 0, 0, wave);
+        __syncthreads();
+        if (nk > 1)
+            stg.dma(p, smem, 1, 1, wave);
+#pragma unroll
+        for (int j = 0; j < JC; ++j)
+            read_w(smem + wpo, 0, j);
+        read_a(smem + apo, 0);
+        split_parts(ra[0], ra[1], a[0]);
+        read_a(smem + apo, 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const float *cur = smem + (kt & 1) * STG, *nxt = smem + ((kt + 1) & 1) * STG;
+            const bool more = kt + 1 < nk;
+            /* chunk 0: the A splits */
+#pragma unroll
+            for (int i = 0; i < IT - 1; ++i) {
+                split_parts(ra[0], ra[1], a[i + 1]);
+                if (i + 2 < IT)
+                    read_a(cur + apo, i + 2);
+                mfma_group(i, 0);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            last_group_refill(0, cur + wpo, 1, true);
+            __builtin_amdgcn_sched_barrier(0);
+            /* middle chunks */
+#pragma unroll
+            for (int c = 1; c < NC - 1; ++c) {
+#pragma unroll
+                for (int i = 0; i < IT - 1; ++i)
+                    mfma_group(i, c);
+                last_group_refill(c, cur + wpo, c + 1, true);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            /* last chunk: W chunk NC-1 is in registers, so tile kt is read completely */
+            __syncthreads();                  /* tile kt read by every wave; tile kt+1 has landed */
+            if (kt + 2 < nk)
+                stg.dma(p, smem, kt & 1, kt + 2, wave);
+            if (more)
+                read_a(nxt + apo, 0);
+            mfma_group(0, NC - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more)
+                split_parts(ra[0], ra[1], a[0]);          /* next tile's A_0: a[0] is dead */
+#pragma unroll
+            for (int i = 1; i < IT - 1; ++i)
+                mfma_group(i, NC - 1);
+            if (more) {
+                interleave();
+                read_a(nxt + apo, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            last_group_refill(NC - 1, nxt + wpo, 0, more);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (NPL != 0) {
         /* K loop pipelined across steps.  With the weights pre-split a step's only VALU work is
          * the A splits, so the barrier can sit before the LAST fragment group (by then every
          * wave has read all of tile t): behind that group's MFMAs the W fragments of tile t+1
@@ -853,13 +968,14 @@ using Tile4 = Tile<256, 256, 4, 4>; /* 16 waves of 64x64                       *
 using Tile5 = Tile<256, 128, 4, 4>; /* 16 waves of 64x32                       */
 using Tile6 = Tile<128, 256, 2, 4>; /*  8 waves of 64x64                       */
 using Tile7 = Tile<256, 256, 2, 2>; /*  4 waves of 128x128, one per SIMD       */
+using Tile8 = Tile<256, 256, 4, 2>; /*  8 waves of 64x128 (pre-split weights: fewer A splits per wave) */
 
 int cfg_override()
 {
     static int v = -2;
     if (v == -2) {
         const char *env = getenv("VIT_HIP_GEMM_CFG");
-        v = (env && env[0] >= '0' && env[0] <= '7') ? env[0] - '0' : -1;
+        v = (env && env[0] >= '0' && env[0] <= '8') ? env[0] - '0' : -1;
     }
     return v;
 }
@@ -1157,10 +1273,11 @@ template <int EPI, int NPL>
 int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
 {
     int c = cfg_override();
-    if (c != 1 && c != 3)
+    /* the 256x256 tile as 8 waves of 64x128 (Tile8: half the A splits per wave) or of 128x64 (Tile3);
+     * VIT_HIP_GEMM_CFG=3 selects the latter */
+    const bool wide_n = c != 3;   /* measured, same box: +4.8 % (exact split) and +7.5 % (fp16 pairs) over Tile3 */
+    if (c != 1)
         c = (p.N % 256 == 0 && p.M >= 4096 && !prefer_small) ? 3 : 1;
-    if (c == 3 && p.N % 256 != 0)
-        c = 1;
     if (c != 3)
         return launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
     static int num_cus = 0, tail = -1;
@@ -1175,7 +1292,8 @@ int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
     const long tiles = (long)mtiles * ntiles, full = tiles / num_cus, rem = tiles % num_cus;
     const int rows_big = (int)(full * num_cus / ntiles) * 256;
     if (!tail || full < 1 || rem == 0 || 4 * rem > 3 * num_cus || rows_big <= 0 || rows_big >= p.M)
-        return launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
+        return wide_n ? launch_mf16<Tile8, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p)
+                      : launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
     GemmParams big = p, rest = p;
     big.M = rows_big;
     rest.M = p.M - rows_big;
@@ -1183,7 +1301,8 @@ int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
     rest.C = static_cast<float *>(p.C) + (size_t)rows_big * p.N;
     if (p.R)
         rest.R = p.R + (size_t)rows_big * p.N;
-    const int rc = launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big);
+    const int rc = wide_n ? launch_mf16<Tile8, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big)
+                          : launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big);
     return rc ? rc : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, rest);
 }
 
