@@ -658,7 +658,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
          *   tile t+1 has landed), DMA of tile t+2; under the last chunk the next tile's A_0 is read
          *   and split into A_0's registers (dead after that chunk's group 0). */
         constexpr int JC = NPL == 3 ? 2 : 4, NC = JT / JC;
-        static_assert(IT >= 3 && JT % JC == 0 && NC >= 2, "W chunks");
+        static_assert(IT >= 2 && JT % JC == 0 && NC >= 2, "W chunks");
         typedef typename PartT<NPL>::type frag_t;
         constexpr int NT6 = NPL == 3 ? 6 : 3;
         const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
@@ -969,13 +969,14 @@ using Tile5 = Tile<256, 128, 4, 4>; /* 16 waves of 64x32                       *
 using Tile6 = Tile<128, 256, 2, 4>; /*  8 waves of 64x64                       */
 using Tile7 = Tile<256, 256, 2, 2>; /*  4 waves of 128x128, one per SIMD       */
 using Tile8 = Tile<256, 256, 4, 2>; /*  8 waves of 64x128 (pre-split weights: fewer A splits per wave) */
+using Tile9 = Tile<128, 128, 4, 1>; /*  4 waves of 32x128, 2 workgroups per CU */
 
 int cfg_override()
 {
     static int v = -2;
     if (v == -2) {
         const char *env = getenv("VIT_HIP_GEMM_CFG");
-        v = (env && env[0] >= '0' && env[0] <= '8') ? env[0] - '0' : -1;
+        v = (env && env[0] >= '0' && env[0] <= '9') ? env[0] - '0' : -1;
     }
     return v;
 }
@@ -1276,10 +1277,12 @@ int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
     /* the 256x256 tile as 8 waves of 64x128 (Tile8: half the A splits per wave) or of 128x64 (Tile3);
      * VIT_HIP_GEMM_CFG=3 selects the latter */
     const bool wide_n = c != 3;   /* measured, same box: +4.8 % (exact split) and +7.5 % (fp16 pairs) over Tile3 */
-    if (c != 1)
+    if (c != 1 && c != 9)
         c = (p.N % 256 == 0 && p.M >= 4096 && !prefer_small) ? 3 : 1;
+    const bool small_wide = cfg_override() != 1;   /* 128x128 as 4 waves of 32x128 (Tile9) unless VIT_HIP_GEMM_CFG=1: -6 % on the out-projection */
     if (c != 3)
-        return launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
+        return small_wide ? launch_mf16<Tile9, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p)
+                          : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
     static int num_cus = 0, tail = -1;
     if (num_cus == 0) {
         int dev = 0;
@@ -1303,7 +1306,10 @@ int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
         rest.R = p.R + (size_t)rows_big * p.N;
     const int rc = wide_n ? launch_mf16<Tile8, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big)
                           : launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big);
-    return rc ? rc : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, rest);
+    if (rc)
+        return rc;
+    return small_wide ? launch_mf16<Tile9, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, rest)
+                      : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, rest);
 }
 
 } // namespace
