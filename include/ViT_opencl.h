@@ -77,7 +77,8 @@ void vit_hip_destroy(vit_hip_ctx *ctx);
  * fc2 weights -- to bfloat16 and accumulates in fp32; the residual stream, attention
  * arithmetic, norms and classifier stay fp32.  Its logits differ from ViT_seq.c by
  * ~1e-2 (tests/test_gpu_parity.py states the tolerance), so it is opt-in:
- * vit_hip_create() uses F32 unless $VIT_HIP_PRECISION=bf16. */
+ * vit_hip_create() (and so the drop-in ViT_opencl) uses F32 unless $VIT_HIP_PRECISION=bf16, or =fp16x2
+ * for F32_FP16X2 below. */
 enum { VIT_PRECISION_F32 = 0, VIT_PRECISION_BF16_GEMM = 1, VIT_PRECISION_FP8_GEMM = 2, VIT_PRECISION_F32_FP16X2 = 3 };
 int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                       int n_tensors, int device, int max_batch, int precision);

@@ -495,6 +495,13 @@ def test_c_driver_over_files_matches_reference_flow(pkg, device, weights, tmp_pa
     r = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     print(r.stdout[-600:], r.stderr[-600:])
     assert r.returncode == 0, "comparator reported differences"
+    # the same flow with the projections emulated on fp16 pairs ($VIT_HIP_PRECISION=fp16x2): same verdict
+    import os
+    r2 = subprocess.run([str(exe), "./Data/input-100.bin", "./Network", "./Data/fp16x2_result.txt"], cwd=tmp_path,
+                        capture_output=True, text=True, timeout=300, env=dict(os.environ, VIT_HIP_PRECISION="fp16x2"))
+    assert r2.returncode == 0, r2.stdout[-400:] + r2.stderr[-400:]
+    assert (tmp_path / "Data" / "fp16x2_result.txt").read_text().splitlines()[0].split("/")[0] == \
+        (tmp_path / "Data" / "opencl_result.txt").read_text().splitlines()[0].split("/")[0]
     gold = np.load(root / "tests" / "golden" / "b16_full_rounded.npz")
     lines = (tmp_path / "Data" / "opencl_result.txt").read_text().splitlines()
     assert len(lines) == 4

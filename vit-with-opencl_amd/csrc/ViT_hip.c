@@ -197,8 +197,11 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
 int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                    int n_tensors, int device, int max_batch)
 {
+    /* F32 unless asked otherwise: "bf16" -> BF16_GEMM, "fp16x2" -> F32_FP16X2 (FP8_GEMM needs a calibration
+     * pass and is only reachable through vit_hip_create_ex) */
     const char *env = getenv("VIT_HIP_PRECISION");
-    const int precision = (env && env[0] == 'b') ? VIT_PRECISION_BF16_GEMM : VIT_PRECISION_F32;
+    const int precision = (env && env[0] == 'b') ? VIT_PRECISION_BF16_GEMM
+                        : (env && strncmp(env, "fp16x2", 6) == 0) ? VIT_PRECISION_F32_FP16X2 : VIT_PRECISION_F32;
     return vit_hip_create_ex(out, cfg, networks, n_tensors, device, max_batch, precision);
 }
 
