@@ -9,6 +9,7 @@ permuted k order, and reductions are trees.  Per-op tolerance is
 class logits within 1e-4 of ViT_seq.c and the same argmax.
 """
 import ctypes as C
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -739,3 +740,38 @@ def test_model_fp8_gemm_mode(pkg, device, weights, golden_full):
     top2 = np.sort(ref, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 4 * np.abs(logits - ref).max(axis=1)
     assert (logits.argmax(1) == ref.argmax(1))[clear].all()
+
+
+# ---- tuning / fallback paths behind environment switches ---------------------------------
+
+
+@pytest.mark.parametrize("env", [
+    {"VIT_HIP_GEMM_FP32": "native", "VIT_HIP_ATTN_MFMA": "fp32"},    # fp32 matrix instruction everywhere
+    {"VIT_HIP_W3": "0"},                                            # weights split inside the loop
+    {"VIT_HIP_W3": "0", "VIT_HIP_GEMM_SCHED": "0"},                 # ... in the compiler's own instruction order
+    {"VIT_HIP_W3": "0", "VIT_HIP_GEMM_MFMA": "32"},                 # ... on the 32x32x16 shape
+    {"VIT_HIP_GEMM_CFG": "3"},                                      # 128x64 wave tiles
+    {"VIT_HIP_GEMM_CFG": "1", "VIT_HIP_GEMM_TAIL": "0"},            # 128x128 tiles of 64x64 waves only
+    {"VIT_HIP_ATTN": "tiled"},                                      # streaming attention kernel on the B/16 shape
+])
+def test_switchable_paths_meet_the_fp32_parity(env, tmp_path):
+    """Every switch is read once per process, so each combination runs in a child process: two
+    images through the whole model against the reference's goldens at the fp32 tolerance."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g\n"
+        "pkg = g.load_package(); cfg = pkg.preset('vit_b_16')\n"
+        "m = pkg.ViTHip(cfg, pkg.synth_weights(cfg, 0), device=0, max_batch=2)\n"
+        "logits, probs = m.forward(pkg.synth_images(cfg, 0, 2)); m.close()\n"
+        "gold = np.load(%r)\n"
+        "err = float(np.abs(logits - gold['logits'][:2]).max())\n"
+        "print('max |dlogit|', err)\n"
+        "assert err <= 1e-4 and (logits.argmax(1) == gold['logits'][:2].argmax(1)).all()\n"
+    ) % (str(root), str(root / "tests" / "golden" / "b16_full.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, f"{env}: {r.stdout[-300:]} {r.stderr[-800:]}"
