@@ -174,6 +174,10 @@ int vh_launch_linear_bf16(vh_stream_t s, void *output, int output_bf16, const vo
                           int doGelu, const float *residual);
 int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *output, int n_images,
                              int tokens, int embed_dim, int num_heads);
+/* In these modes the attention's two products run on fp16-rounded Q, K, V and P (11-bit operands, fp32
+ * accumulation and softmax; far inside the modes' tolerances); _bf16 writes bf16, _f16 writes fp32. */
+int vh_launch_attention_f16(vh_stream_t s, const float *qkv, float *output, int n_images,
+                            int tokens, int embed_dim, int num_heads);
 
 /* ---- fp8 (OCP e4m3) operand variants (BASELINE config 5) ----
  * No reference counterpart.  Values are stored as x / scale rounded to e4m3 (saturating at

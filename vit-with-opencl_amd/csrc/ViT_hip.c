@@ -448,7 +448,7 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_fp8(s, ctx->x, lw[0], lw[1], ctx->y, 1.0f / as[0], rows, E, E, E, c->eps));
         OP(VIT_OP_QKV, vh_launch_linear_fp8(s, ctx->qkv, 0, lw8[2], ctx->y, lw[3], cs[2], 1.0f, rows, E, 3 * E, 0, NULL));
         /* attention in fp32, then its output quantised for the out-projection (one timed operator) */
-        OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads)) != 0 ? rc :
+        OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads)) != 0 ? rc :
                              vh_launch_convert_fp8(s, ctx->attn, ctx->y, (size_t)rows * E, 1.0f / as[1]));
         OP(VIT_OP_OUT_PROJ, vh_launch_linear_fp8(s, ctx->x, 0, lw8[4], ctx->y, lw[5], cs[4], 1.0f, rows, E, E, 0, ctx->x));
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_fp8(s, ctx->x, lw[6], lw[7], ctx->y, 1.0f / as[2], rows, E, E, E, c->eps));

@@ -61,7 +61,9 @@ typedef __attribute__((address_space(3))) void *lptr_t;
  * (fp32 operands, 1/16 of the 16-bit rate).  3: every operand fragment split exactly into three
  * bf16 parts in registers, six v_mfma_f32_32x32x16_bf16 per block (the GEMMs' SPLIT3, same
  * accuracy, 2.67x the fp32 MFMA rate -- the kernel turns from MFMA-bound to VALU-bound).
- * 2: two fp16 parts, three products (the opt-in emulation mode, fp32_split.h). */
+ * 2: two fp16 parts, three products (the opt-in emulation mode, fp32_split.h).  1: operands rounded
+ * to fp16, one product -- only for the reduced-precision GEMM modes (bf16 / fp8 operands), whose
+ * tolerances it sits far inside (11-bit operands against their 8- and 4-bit ones). */
 template <int NKT, bool OUTBF16, int NPL> /* NKT 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT */
 __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__restrict__ qkv,
                                                                 void *__restrict__ out, int T,
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
          * QK^T tiles so that issuing ~15 DMA instructions does not delay their MFMAs. */
         /* hold-back of a SIMD's second wave ~ one Q.K^T phase of the first: 64 cycles per key with the
          * fp32 MFMA, about a third of that on the split forms */
-        constexpr int LATE_CYCLES_PER_KEY = (NPL == 0 ? 64 : NPL == 3 ? 24 : 14) * LATE_SCALE / 100;
+        constexpr int LATE_CYCLES_PER_KEY = (NPL == 0 ? 64 : NPL == 3 ? 24 : NPL == 2 ? 14 : 8) * LATE_SCALE / 100;
         const bool late = NKT > 4 && wave >= 4;
         const float *v_src = head_base(item, 2);
         const float *k_src = head_base(next < n_items ? next : item, 1);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
                     typename PartT<NPL>::type kp[NPL];
                     split_parts(kfrag(2 * g), kfrag(2 * g + 1), kp);
 #pragma unroll
-                    for (int t = 0; t < (NPL == 3 ? 6 : 3); ++t)
+                    for (int t = 0; t < n_terms<NPL>(); ++t)
                         s[j] = mfma_part(kp[term_w<NPL>(t)], qp[g][term_a<NPL>(t)], s[j]);
                 }
             }
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
                         typename PartT<NPL>::type vq[NPL];
                         split_parts(vlo, vhi, vq);
 #pragma unroll
-                        for (int tt = 0; tt < (NPL == 3 ? 6 : 3); ++tt)
+                        for (int tt = 0; tt < n_terms<NPL>(); ++tt)
                             o[dt] = mfma_part(vq[term_w<NPL>(tt)], pp[term_a<NPL>(tt)], o[dt]);
                     }
                 }
@@ -397,12 +399,16 @@ int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, i
     return 0;
 }
 
-/* arith: 0 = fp32 MFMA, 3 = exact three-part bf16 split (default), 2 = two fp16 parts (emulation mode) */
+/* arith: 0 = fp32 MFMA, 3 = exact three-part bf16 split (default), 2 = two fp16 parts (emulation mode),
+ * 1 = operands rounded to fp16 (the bf16 / fp8 GEMM modes) */
 template <int NKT>
 int launch(hipStream_t st, const float *qkv, void *out, int out_bf16, int arith, int n_images, int T, int E, int H)
 {
     if (arith == 2 && !out_bf16)
         return launch_k<NKT, false, 2>(st, qkv, out, n_images, T, E, H);
+    if (arith == 1)
+        return out_bf16 ? launch_k<NKT, true, 1>(st, qkv, out, n_images, T, E, H)
+                        : launch_k<NKT, false, 1>(st, qkv, out, n_images, T, E, H);
     if (arith == 0)
         return out_bf16 ? launch_k<NKT, true, 0>(st, qkv, out, n_images, T, E, H)
                         : launch_k<NKT, false, 0>(st, qkv, out, n_images, T, E, H);
@@ -457,7 +463,13 @@ extern "C" int vh_launch_attention(vh_stream_t s, const float *qkv, float *outpu
 extern "C" int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *output, int n_images,
                                         int tokens, int embed_dim, int num_heads)
 {
-    return launch_attention(s, qkv, output, 1, 3, n_images, tokens, embed_dim, num_heads);
+    /* the bf16-operand GEMM mode: Q, K, V, P rounded to fp16 for the two products (VIT_HIP_ATTN_LOWP=0: exact) */
+    static int lowp = -1;
+    if (lowp < 0) {
+        const char *env = getenv("VIT_HIP_ATTN_LOWP");
+        lowp = (env && env[0] == '0') ? 0 : 1;
+    }
+    return launch_attention(s, qkv, output, 1, lowp ? 1 : 3, n_images, tokens, embed_dim, num_heads);
 }
 
 /* The emulation mode's attention: Q.K^T and P.V on two fp16 parts / three products (kernelHandler.h,
@@ -466,4 +478,11 @@ extern "C" int vh_launch_attention_h2(vh_stream_t s, const float *qkv, float *ou
                                       int tokens, int embed_dim, int num_heads)
 {
     return launch_attention(s, qkv, output, 0, 2, n_images, tokens, embed_dim, num_heads);
+}
+
+/* fp32 in, fp32 out, Q / K / V / P rounded to fp16 for the two products: the fp8-operand GEMM mode. */
+extern "C" int vh_launch_attention_f16(vh_stream_t s, const float *qkv, float *output, int n_images,
+                                       int tokens, int embed_dim, int num_heads)
+{
+    return launch_attention(s, qkv, output, 0, 1, n_images, tokens, embed_dim, num_heads);
 }

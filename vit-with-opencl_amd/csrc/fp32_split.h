@@ -40,6 +40,7 @@ __device__ __forceinline__ void split8(const f32x4 &u, const f32x4 &v, bf16x8 &p
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 template <int NPL> struct PartT { typedef bf16x8 type; };
 template <> struct PartT<2> { typedef half8 type; };
+template <> struct PartT<1> { typedef half8 type; };   /* one fp16 part: operands ROUNDED to fp16 (reduced-precision modes only) */
 
 __device__ __forceinline__ void split_parts(const f32x4 &u, const f32x4 &v, bf16x8 (&o)[3])
 {
@@ -54,6 +55,12 @@ __device__ __forceinline__ void split_parts(const f32x4 &u, const f32x4 &v, half
         o[0][e] = h;
         o[1][e] = (_Float16)(x - (float)h);
     }
+}
+__device__ __forceinline__ void split_parts(const f32x4 &u, const f32x4 &v, half8 (&o)[1])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        o[0][e] = (_Float16)(e < 4 ? u[e] : v[e - 4]);
 }
 __device__ __forceinline__ f32x4 mfma_part(bf16x8 w, bf16x8 a, f32x4 c)
 {
@@ -73,13 +80,14 @@ __device__ __forceinline__ f32x16 mfma_part(half8 w, half8 a, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, c, 0, 0, 0);
 }
 /* (w part, a part) of product t, smallest terms first */
+template <int NPL> __device__ __forceinline__ constexpr int n_terms() { return NPL == 3 ? 6 : NPL == 2 ? 3 : 1; }
 template <int NPL> __device__ __forceinline__ constexpr int term_w(int t)
 {
-    return NPL == 3 ? (t == 0 || t == 3 || t == 5 ? 0 : t == 1 ? 2 : 1) : (t == 0 ? 1 : 0);
+    return NPL == 3 ? (t == 0 || t == 3 || t == 5 ? 0 : t == 1 ? 2 : 1) : NPL == 2 ? (t == 0 ? 1 : 0) : 0;
 }
 template <int NPL> __device__ __forceinline__ constexpr int term_a(int t)
 {
-    return NPL == 3 ? (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0) : (t == 1 ? 1 : 0);
+    return NPL == 3 ? (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0) : NPL == 2 ? (t == 1 ? 1 : 0) : 0;
 }
 
 #endif

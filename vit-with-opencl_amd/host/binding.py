@@ -36,7 +36,7 @@ EXPORTS = [
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_profile_select", "vit_hip_create_ex", "vit_hip_precision",
     "vh_launch_convert_bf16", "vh_launch_layer_norm_bf16", "vh_launch_linear_bf16", "vh_launch_attention_bf16",
     "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_launch_split3_planes", "vh_launch_linear_w3",
-    "vh_launch_split2h_planes", "vh_launch_linear_h2", "vh_launch_attention_h2",
+    "vh_launch_split2h_planes", "vh_launch_linear_h2", "vh_launch_attention_h2", "vh_launch_attention_f16",
     "vh_launch_convert_fp8", "vh_launch_quantize_rows_fp8", "vh_launch_absmax", "vh_launch_scale_vector",
     "vh_launch_layer_norm_fp8", "vh_launch_linear_fp8", "vit_hip_calibrate_fp8", "vit_hip_fp8_scales",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
@@ -140,6 +140,7 @@ def lib() -> C.CDLL:
     L.vh_launch_linear.argtypes = [voidp] + [voidp] * 4 + [i, i, i, i, voidp]
     L.vh_launch_attention.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_attention_h2.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_attention_f16.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_split3_planes.argtypes = [voidp, voidp, voidp, i, i]
     L.vh_launch_linear_w3.argtypes = [voidp] + [voidp] * 4 + [i, i, i, i, voidp]
     L.vh_launch_split2h_planes.argtypes = [voidp, voidp, voidp, i, i, C.c_float]
