@@ -282,14 +282,14 @@ def main() -> None:
         roofline = {"bound": "mfma",
                     "kernel": "%s fc1 GEMM (M=%d N=%d K=%d); %s" %
                     ("gemm_f32_kernel<...EPI_GELU...>" if native or args.dtype != "f32" and False else
-                     "gemm_mf16_kernel<Tile<256,256,2,4>,A_ROWS,EPI_GELU,...>",
+                     "gemm_mf16_kernel<Tile<256,256,4,2>,A_ROWS,EPI_GELU,...> (+ its Tile<128,128,4,1> launch for the last partial round)",
                      B * tokens, cfg.mlp_hidden, cfg.embed_dim,
                      "native fp32 MFMA (v_mfma_f32_32x32x2_f32), Tile<256,256,4,4>" if native else
                      "bf16 operands on v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16" else
                      "e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8" if args.dtype == "fp8" else
                      "fp32 operands as two fp16 parts, 3 x v_mfma_f32_16x16x32_f16 per block (not exact)"
                      if args.dtype == "f32_fp16x2" else
-                     "exact 3-way bf16 split of fp32 operands, 6 x v_mfma_f32_16x16x32_bf16 per block"),
+                     "exact 3-way bf16 split of fp32 operands (weights pre-split), 6 x v_mfma_f32_16x16x32_bf16 per block"),
                     "peak_basis": peak_note,
                     "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(achieved / peak_tf, 4), "traffic": traffic,
