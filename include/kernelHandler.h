@@ -130,6 +130,30 @@ int vh_launch_linear_w3(vh_stream_t s, float *output, const void *weight_planes,
                         const float *bias, int rowA, int colA, int colB, int doGelu,
                         const float *residual);
 
+/* ---- both operands pre-split ("P3"): the default fp32 path of the four big projections ----
+ * The exact three-way split x = p0 + p1 + p2 of an fp32 matrix [rows][cols], stored as bfloat16 planes
+ *     planes[cols/32][3][rows][32]      (K step, part, row, element; 6 bytes per value)
+ * -- the layout vh_launch_split3_planes gives the weights.  When the PRODUCER of a GEMM input writes
+ * this format (vh_launch_layer_norm_p3, vh_launch_attention_p3, vh_launch_linear_p3 with output_planes),
+ * the GEMM's K loop contains no split arithmetic at all: matrix instructions, LDS reads and loads only
+ * (csrc/gemm_p3.hip).  Same six partial products per block, in the same order, as vh_launch_linear /
+ * vh_launch_linear_w3: results are identical bit for bit.  No reference counterpart (format plumbing
+ * around ll.cl:7 / multihead.cl:3 / layer_norm.cl:3); rows < 2^26, cols % 32 == 0, 16-byte aligned. */
+int vh_launch_split3_rows(vh_stream_t s, const float *input, void *planes, int rows, int cols);
+int vh_launch_merge3_rows(vh_stream_t s, const void *planes, float *output, int rows, int cols); /* exact inverse */
+/* vh_launch_layer_norm writing planes [embed_dim/32][3][rows][32] */
+int vh_launch_layer_norm_p3(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                            void *out_planes, int rows, int embed_dim, long in_row_stride, double eps);
+/* vh_launch_attention writing planes [embed_dim/32][3][n_images*tokens][32] (head_dim 64, tokens <= 208) */
+int vh_launch_attention_p3(vh_stream_t s, const float *qkv, void *out_planes, int n_images, int tokens,
+                           int embed_dim, int num_heads);
+/* vh_launch_linear on planes: input_planes [colA/32][3][rowA][32], weight_planes [colA/32][3][colB][32];
+ * output fp32 [rowA][colB], or (output_planes != 0, no residual) planes [colB/32][3][rowA][32].
+ * colA % 64 == 0, colB % 128 == 0. */
+int vh_launch_linear_p3(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
+                        const void *input_planes, const float *bias, int rowA, int colA, int colB,
+                        int doGelu, const float *residual);
+
 /* fp32 emulation with two fp16 parts per operand and three products (the "3 x TF32" scheme on
  * fp16: a = a0 + a1 + eps, |eps| <= 2^-22 |a|; a.w ~ a0w0 + a0w1 + a1w0, fp32 accumulation).  NOT
  * exact -- operands keep 22 of their 24 significant bits -- but its truncation error (~8e-8 of the

@@ -55,6 +55,7 @@ struct vit_hip_ctx
     void *w3_slab;
     void **w3;          /* per tensor index (NULL: use the fp32 tensor) */
     float *w3_scale;    /* F32_FP16X2: per tensor index, the power of two its fp16 parts were scaled by */
+    int use_p3;         /* F32: GEMM inputs travel as three-part bf16 planes (y, attn, hid hold 6 bytes per value) */
     void *w8_slab;
     void **w8;          /* per tensor index */
     float *wscale_slab; /* per tensor index: [out_features] row scales, then [out_features] a_scale*row scale */
@@ -387,13 +388,21 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
     const size_t E = (size_t)cfg->embed_dim, F = (size_t)cfg->mlp_hidden, NC = (size_t)cfg->num_classes;
     const size_t rows = (size_t)max_batch * ctx->tokens;
     const size_t img = (size_t)cfg->in_chans * cfg->img_size * cfg->img_size;
+    {   /* the default fp32 path: every GEMM input is written by its producer as the exact three-part
+         * bf16 split (csrc/gemm_p3.hip), 6 bytes per value; VIT_HIP_P3=0 keeps fp32 activations and
+         * the in-loop split (csrc/gemm_mfma.hip) */
+        const char *env_p3 = getenv("VIT_HIP_P3");
+        ctx->use_p3 = ctx->w3_slab && precision == VIT_PRECISION_F32 && !(env_p3 && env_p3[0] == '0') &&
+                      rows * 64 <= 0xffffffffull;
+    }
+    const size_t act = ctx->use_p3 ? 6 : sizeof(float);   /* bytes per GEMM-input value */
     TRY(vh_malloc((void **)&ctx->x, rows * E * sizeof(float)));
-    TRY(vh_malloc((void **)&ctx->y, rows * E * sizeof(float)));
-    TRY(vh_malloc((void **)&ctx->attn, rows * E * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->y, rows * E * act));
+    TRY(vh_malloc((void **)&ctx->attn, rows * E * act));
     TRY(vh_malloc((void **)&ctx->qkv, rows * 3 * E * sizeof(float)));
     {   /* patch geometries that need gathered rows (H/14) borrow the MLP hidden buffer, idle at that point */
         const size_t ws = vh_patch_embed_workspace(max_batch, cfg->in_chans, cfg->img_size, cfg->patch_size, cfg->embed_dim);
-        const size_t hid_bytes = rows * F * sizeof(float);
+        const size_t hid_bytes = rows * F * act;
         ctx->ws_bytes = ws > hid_bytes ? ws : hid_bytes;
         TRY(vh_malloc((void **)&ctx->hid, ctx->ws_bytes));
     }
@@ -481,7 +490,23 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         OP(VIT_OP_FC1, vh_launch_linear_bf16(s, ctx->hid, 1, lw16[8], ctx->y, lw[9], rows, E, F, 1, NULL));
         OP(VIT_OP_FC2, vh_launch_linear_bf16(s, ctx->x, 0, lw16[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
     }
-    for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32; ++l) {
+    for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32 && ctx->use_p3; ++l) {
+        /* GEMM inputs as pre-split planes: LayerNorm, attention and the fc1 epilogue write them */
+        float **lw = w + 4 + 12 * l;
+        void **l3 = ctx->w3 + 4 + 12 * l;
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, c->eps));
+        OP(VIT_OP_QKV, vh_launch_linear_p3(s, ctx->qkv, 0, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+        if (E == 64 * c->num_heads && T <= 208)
+            OP(VIT_OP_ATTENTION, vh_launch_attention_p3(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+        else   /* shapes of the streaming attention kernel: fp32 output (into the idle MLP buffer), then split */
+            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                                 vh_launch_split3_rows(s, ctx->hid, ctx->attn, rows, E));
+        OP(VIT_OP_OUT_PROJ, vh_launch_linear_p3(s, ctx->x, 0, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, c->eps));
+        OP(VIT_OP_FC1, vh_launch_linear_p3(s, ctx->hid, 1, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+        OP(VIT_OP_FC2, vh_launch_linear_p3(s, ctx->x, 0, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+    }
+    for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32 && !ctx->use_p3; ++l) {
         float **lw = w + 4 + 12 * l; /* ln1 w,b; in w,b; out w,b; ln2 w,b; fc1 w,b; fc2 w,b */
         float *amax = ctx->calibrating ? ctx->d_amax + 4 * l : NULL; /* fp8 calibration: record max |GEMM input| */
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));

@@ -64,7 +64,8 @@ typedef __attribute__((address_space(3))) void *lptr_t;
  * 2: two fp16 parts, three products (the opt-in emulation mode, fp32_split.h).  1: operands rounded
  * to fp16, one product -- only for the reduced-precision GEMM modes (bf16 / fp8 operands), whose
  * tolerances it sits far inside (11-bit operands against their 8- and 4-bit ones). */
-template <int NKT, bool OUTBF16, int NPL> /* NKT 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT */
+template <int NKT, int OUTK, int NPL> /* NKT 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT; OUTK: 0 fp32, 1 bf16,
+                                         * 3 the three-part bf16 split as planes [E/32][3][n_images*T][32] (gemm_p3.hip) */
 __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__restrict__ qkv,
                                                                 void *__restrict__ out, int T,
                                                                 int E, int H, int n_items, int RB)
@@ -348,15 +349,45 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
             load_q(next);
         }
 
-        if (q < T) {
+        if (OUTK == 3) {
+            /* Consumed only by the pre-split output projection: planes [E/32][3][rows][32], K step 2h + dt.
+             * A lane holds d = 8g + 4lh .. +3 (8 bytes per part); one half-wave exchange per dword
+             * (v_permlane32_swap) gives the lower half the 16 bytes of group g and the upper half those of
+             * group g+1.  Lanes l and l + 32 share a query, so the guard keeps pairs together. */
+            if (q < T) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const size_t prow = (size_t)(n_items / H) * T;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    u32x2 pg[4][3];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 part[3];
+                        split4(f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]}, part[0], part[1], part[2]);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            pg[g][pl] = __builtin_bit_cast(u32x2, part[pl]);
+                    }
+                    char *d3 = static_cast<char *>(out) + ((size_t)(2 * h + dt) * 3 * prow + (size_t)b * T + q) * 64 + 16 * lh;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int g = 0; g < 4; g += 2) {
+                            const auto r0 = __builtin_amdgcn_permlane32_swap(pg[g][pl][0], pg[g + 1][pl][0], false, false);
+                            const auto r1 = __builtin_amdgcn_permlane32_swap(pg[g][pl][1], pg[g + 1][pl][1], false, false);
+                            *reinterpret_cast<u32x4 *>(d3 + (size_t)pl * prow * 64 + 16 * g) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                        }
+                }
+            }
+        } else if (q < T) {
             const size_t off = ((size_t)b * T + q) * E + (size_t)h * HD + 4 * lh;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-                    if (OUTBF16) { /* consumed only by the bf16-operand output projection */
-                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    if (OUTK == 1) { /* consumed only by the bf16-operand output projection */
                         bf16x4 v16 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                         *reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(out) + off + dt * 32 + 8 * g) = v16;
                     } else {
@@ -371,7 +402,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
     }
 }
 
-template <int NKT, bool OUTBF16, int NPL>
+template <int NKT, int OUTK, int NPL>
 int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, int E, int H)
 {
     /* rows per buffer: whole register groups of keys (8 for the fp32 MFMA, 16 for the split forms), whole 4-row DMA pieces */
@@ -379,7 +410,7 @@ int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, i
     const size_t lds = sizeof(float) * 3 * RB * HD + 64;
     static bool attr_set = false;
     if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)attention_f32_kernel<NKT, OUTBF16, NPL>,
+        VH_TRY(hipFuncSetAttribute((const void *)attention_f32_kernel<NKT, OUTK, NPL>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         attr_set = true;
     }
@@ -393,7 +424,7 @@ int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, i
     }
     const int n_items = n_images * H;
     const int grid = n_items < num_cus ? n_items : num_cus;
-    hipLaunchKernelGGL((attention_f32_kernel<NKT, OUTBF16, NPL>), dim3(grid), dim3(64 * NKT), lds, st, qkv, out,
+    hipLaunchKernelGGL((attention_f32_kernel<NKT, OUTK, NPL>), dim3(grid), dim3(64 * NKT), lds, st, qkv, out,
                        T, E, H, n_items, RB);
     VH_LAUNCH_CHECK("attention_f32_kernel");
     return 0;
@@ -404,6 +435,8 @@ int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, i
 template <int NKT>
 int launch(hipStream_t st, const float *qkv, void *out, int out_bf16, int arith, int n_images, int T, int E, int H)
 {
+    if (out_bf16 == 3)   /* planes for the pre-split output projection (exact split only) */
+        return launch_k<NKT, 3, 3>(st, qkv, out, n_images, T, E, H);
     if (arith == 2 && !out_bf16)
         return launch_k<NKT, false, 2>(st, qkv, out, n_images, T, E, H);
     if (arith == 1)
@@ -433,7 +466,7 @@ static int launch_attention(vh_stream_t s, const float *qkv, void *output, int o
         const char *env = getenv("VIT_HIP_ATTN");
         force_tiled = (env && env[0] == 't') ? 1 : 0;
     }
-    if (embed_dim != num_heads * HD || tokens > MAX_ROWS || force_tiled)
+    if (embed_dim != num_heads * HD || tokens > MAX_ROWS || (force_tiled && out_bf16 != 3))
         return vh_attention_tiled(s, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
     static int native = -1;
     if (native < 0) {
@@ -470,6 +503,16 @@ extern "C" int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *o
         lowp = (env && env[0] == '0') ? 0 : 1;
     }
     return launch_attention(s, qkv, output, 1, lowp ? 1 : 3, n_images, tokens, embed_dim, num_heads);
+}
+
+/* The fp32 attention writing its output as the three-part split planes [E/32][3][n_images*tokens][32] that
+ * vh_launch_linear_p3 reads (same values as vh_launch_attention, split exactly). */
+extern "C" int vh_launch_attention_p3(vh_stream_t s, const float *qkv, void *out_planes, int n_images,
+                                      int tokens, int embed_dim, int num_heads)
+{
+    if (embed_dim != num_heads * HD || tokens > MAX_ROWS)
+        return vh_fail(1, "vh_launch_attention_p3: needs head_dim 64 and tokens <= %d", MAX_ROWS);
+    return launch_attention(s, qkv, out_planes, 3, 3, n_images, tokens, embed_dim, num_heads);
 }
 
 /* The emulation mode's attention: Q.K^T and P.V on two fp16 parts / three products (kernelHandler.h,

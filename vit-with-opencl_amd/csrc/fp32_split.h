@@ -30,6 +30,23 @@ __device__ __forceinline__ void split8(const f32x4 &u, const f32x4 &v, bf16x8 &p
     }
 }
 
+/* The same split of four values (8-byte parts): producers that hold four consecutive elements per lane. */
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(const f32x4 &u, bf16x4 &p0, bf16x4 &p1, bf16x4 &p2)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = u[e];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        p0[e] = h;
+        p1[e] = m;
+        p2[e] = (__bf16)r2;
+    }
+}
+
 /* Parts of a split fp32 operand, per decomposition:
  *   NPL = 3: x = p0 + p1 + p2 exactly, bf16 parts; six products (all of weight >= 2^-16)
  *   NPL = 2: x = p0 + p1 + eps, fp16 parts (2 x 11 significant bits; |eps| <= 2^-22 |x|, fp16

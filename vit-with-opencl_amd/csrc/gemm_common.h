@@ -1,0 +1,73 @@
+/*
+ * gemm_common.h -- pieces shared by the GEMM translation units (gemm_mfma.hip, gemm_p3.hip):
+ * the XCD-aware blockIdx -> tile map and the fc1 GELU epilogue.  Internal.
+ */
+#ifndef VIT_HIP_GEMM_COMMON_H
+#define VIT_HIP_GEMM_COMMON_H
+
+#include "vit_kernels.h"
+
+/* Bijective XCD remap (blocks b and b+8 share an XCD; which one is not known
+ * and not needed): XCD x gets a contiguous run of tiles. */
+__device__ __forceinline__ int xcd_tile(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+/* GELU for the fc1 epilogue: 0.5*x*(1+erf(x/sqrt(2))), ViT_seq.c:285 / ll.cl:4.
+ * The scalar loop calls libm erff; a device libm erff is two divergent branches of
+ * ~50 VALU instructions each, which made this epilogue a third of the fc1 kernel
+ * (42 us per 128x128 tile).  GELU only needs erf to ABSOLUTE accuracy (it forms
+ * 1 + erf), so one branch-free form serves every x:
+ *     erf(a) = sign(a) * (1 - 2^(-t*S(t))),  t = min(|a|, 4),  S(t) = -log2(erfc(t))/t
+ * with S a degree-10 least-squares fit on Chebyshev nodes (tools/fit_gelu.py):
+ * max |erf - exact| = 8.2e-8, max |gelu - scalar fp32 formula with glibc erff| = 2.4e-7
+ * (half an ulp at |x| = 8; that scalar formula is itself 4.5e-7 from exact).
+ * The division by sqrt(2) is a multiplication by its fp32 reciprocal. */
+__device__ __forceinline__ float gelu_exact(float x)
+{
+    const float a = x * 0.70710678118654752f;
+    const float t = fminf(fabsf(a), 4.0f);
+    float s = -1.434945176e-07f;
+    s = __builtin_fmaf(s, t, 3.633770575e-06f);
+    s = __builtin_fmaf(s, t, -4.095854820e-05f);
+    s = __builtin_fmaf(s, t, 2.688577224e-04f);
+    s = __builtin_fmaf(s, t, -1.106124371e-03f);
+    s = __builtin_fmaf(s, t, 2.616208047e-03f);
+    s = __builtin_fmaf(s, t, -3.566097876e-04f);
+    s = __builtin_fmaf(s, t, -2.759680524e-02f);
+    s = __builtin_fmaf(s, t, 1.482741833e-01f);
+    s = __builtin_fmaf(s, t, 9.184474349e-01f);
+    s = __builtin_fmaf(s, t, 1.627907038e+00f);
+    const float erf_a = copysignf(1.0f - __builtin_amdgcn_exp2f(-(t * s)), a);
+    return 0.5f * x * (1.0f + erf_a);
+}
+
+/* The same GELU on two values at once: every step is a packed instruction (v_pk_mul_f32,
+ * v_pk_fma_f32, ...), half the VALU issue slots of the scalar form, the same bits per element. */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_exact2(f32x2 x)
+{
+    const f32x2 a = x * 0.70710678118654752f;
+    const f32x2 t = __builtin_elementwise_min(__builtin_elementwise_abs(a), f32x2{4.0f, 4.0f});
+    auto k = [](float c) { return f32x2{c, c}; };
+    f32x2 s = k(-1.434945176e-07f);
+    s = __builtin_elementwise_fma(s, t, k(3.633770575e-06f));
+    s = __builtin_elementwise_fma(s, t, k(-4.095854820e-05f));
+    s = __builtin_elementwise_fma(s, t, k(2.688577224e-04f));
+    s = __builtin_elementwise_fma(s, t, k(-1.106124371e-03f));
+    s = __builtin_elementwise_fma(s, t, k(2.616208047e-03f));
+    s = __builtin_elementwise_fma(s, t, k(-3.566097876e-04f));
+    s = __builtin_elementwise_fma(s, t, k(-2.759680524e-02f));
+    s = __builtin_elementwise_fma(s, t, k(1.482741833e-01f));
+    s = __builtin_elementwise_fma(s, t, k(9.184474349e-01f));
+    s = __builtin_elementwise_fma(s, t, k(1.627907038e+00f));
+    const f32x2 ts = t * s;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-ts[0]), __builtin_amdgcn_exp2f(-ts[1])};
+    const f32x2 erf_a = __builtin_elementwise_copysign(k(1.0f) - e, a);
+    return (x * 0.5f) * (k(1.0f) + erf_a);
+}
+
+#endif

@@ -15,6 +15,7 @@
  */
 #include "kernelHandler.h"
 #include "vit_kernels.h"
+#include "fp32_split.h"
 
 namespace {
 
@@ -71,7 +72,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(out) + (size_t)row * out_stride);
     bf16x4 *dst16 = reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(out) + (size_t)row * out_stride);
     unsigned *dst8 = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(out) + (size_t)row * out_stride);
@@ -94,6 +94,73 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             }
         }
     }
+}
+
+/* LayerNorm whose only consumer is the pre-split GEMM (gemm_p3.hip): the result is split exactly into three
+ * bf16 parts and written as planes [E/32][3][rows][32].  One wave per row as above (same arithmetic, same
+ * summation order: identical values), 16 rows per workgroup; the parts go through an LDS image of the
+ * planes' own order, [K step][part][16 rows][64 B], so that every global store instruction writes one
+ * contiguous, aligned KiB (16 rows x 64 B of one K step and part) instead of eight 64-byte pieces 19 MB apart. */
+constexpr int LN3_ROWS = 16;
+template <int NV>
+__global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float *__restrict__ in,
+                                                                    const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta,
+                                                                    char *__restrict__ planes, int rows, int E,
+                                                                    long in_stride, double eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char ln_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * LN3_ROWS, row = row0 + wave;
+    const int nvec = E >> 2;
+    if (row < rows) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)row * in_stride);
+        f32x4 x[NV];
+        float sum = 0.0f, sq = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int idx = c * 64 + lane;
+            if (idx < nvec) {
+                x[c] = src[idx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sum += x[c][e];
+                    sq += x[c][e] * x[c][e];
+                }
+            }
+        }
+        sum = wave_sum(sum);
+        sq = wave_sum(sq);
+        const float mean = sum / (float)E;
+        const float var = sq / (float)E - mean * mean;
+        const float inv_std = 1.0f / sqrtf((float)((double)var + eps));
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+        const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int idx = c * 64 + lane;
+            if (idx < nvec) {
+                const f32x4 g = g4[idx], bb = b4[idx];
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    y[e] = (x[c][e] - mean) * inv_std * g[e] + bb[e];
+                bf16x4 part[3];
+                split4(y, part[0], part[1], part[2]);
+                char *d = ln_lds + ((size_t)(idx >> 3) * 3 * LN3_ROWS + wave) * 64 + 8 * (idx & 7);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<bf16x4 *>(d + pl * LN3_ROWS * 64) = part[pl];
+            }
+        }
+    }
+    __syncthreads();
+    /* copy-out: piece = (K step, part) = 1 KiB = 16 rows x 64 B; lane l moves 16 bytes of row l / 4 */
+    const int pieces = (E >> 5) * 3;
+    if (row0 + (lane >> 2) < rows)
+        for (int pc = wave; pc < pieces; pc += LN3_ROWS)
+            *reinterpret_cast<f32x4 *>(planes + ((size_t)pc * rows + row0) * 64 + 16 * lane) =
+                *reinterpret_cast<const f32x4 *>(ln_lds + pc * 1024 + 16 * lane);
 }
 
 constexpr int SM_THREADS = 256;
@@ -193,6 +260,41 @@ extern "C" int vh_launch_layer_norm_bf16(vh_stream_t s, const float *input, cons
 {
     return launch_layer_norm(s, input, weight, bias, output, 1, 1.0f, rows, embed_dim, in_row_stride,
                              out_row_stride, eps);
+}
+
+extern "C" int vh_launch_layer_norm_p3(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                                       void *out_planes, int rows, int embed_dim, long in_row_stride, double eps)
+{
+    if (!input || !weight || !bias || !out_planes)
+        return vh_fail(1, "vh_launch_layer_norm_p3: null pointer argument");
+    if (rows <= 0 || embed_dim <= 0 || embed_dim % 32 != 0 || embed_dim > 2048 || ((uintptr_t)out_planes & 15))
+        return vh_fail(1, "vh_launch_layer_norm_p3: embed_dim=%d must be a multiple of 32, <= 2048, planes 16-byte aligned", embed_dim);
+    if (in_row_stride % 4 != 0 || in_row_stride < embed_dim)
+        return vh_fail(1, "vh_launch_layer_norm_p3: row stride must be a multiple of 4 floats and >= embed_dim");
+    const int nv = (embed_dim / 4 + 63) / 64;
+    const size_t lds = (size_t)(embed_dim / 32) * 3 * LN3_ROWS * 64;
+    const dim3 grid((rows + LN3_ROWS - 1) / LN3_ROWS), block(64 * LN3_ROWS);
+    hipStream_t st = (hipStream_t)s;
+#define VH_LN3(NV)                                                                                        \
+    do {                                                                                                  \
+        static bool attr_set[16];                                                                         \
+        int dev = 0;                                                                                      \
+        VH_TRY(hipGetDevice(&dev));                                                                       \
+        if (dev >= 0 && dev < 16 && !attr_set[dev]) {                                                     \
+            VH_TRY(hipFuncSetAttribute((const void *)layernorm_p3_kernel<NV>,                             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));          \
+            attr_set[dev] = true;                                                                         \
+        }                                                                                                 \
+        hipLaunchKernelGGL((layernorm_p3_kernel<NV>), grid, block, lds, st, input, weight, bias,          \
+                           static_cast<char *>(out_planes), rows, embed_dim, in_row_stride, eps);         \
+    } while (0)
+    if (nv <= 3) VH_LN3(3);
+    else if (nv <= 4) VH_LN3(4);
+    else if (nv <= 5) VH_LN3(5);
+    else VH_LN3(8);
+#undef VH_LN3
+    VH_LAUNCH_CHECK("layernorm_p3_kernel");
+    return 0;
 }
 
 extern "C" int vh_launch_layer_norm_fp8(vh_stream_t s, const float *input, const float *weight,

@@ -39,6 +39,8 @@ EXPORTS = [
     "vh_launch_split2h_planes", "vh_launch_linear_h2", "vh_launch_attention_h2", "vh_launch_attention_f16",
     "vh_launch_convert_fp8", "vh_launch_quantize_rows_fp8", "vh_launch_absmax", "vh_launch_scale_vector",
     "vh_launch_layer_norm_fp8", "vh_launch_linear_fp8", "vit_hip_calibrate_fp8", "vit_hip_fp8_scales",
+    "vh_launch_split3_rows", "vh_launch_merge3_rows", "vh_launch_layer_norm_p3", "vh_launch_attention_p3",
+    "vh_launch_linear_p3",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
     "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
     "vit_write_result_file", "vit_compare_rows",
@@ -146,6 +148,11 @@ def lib() -> C.CDLL:
     L.vh_launch_split2h_planes.argtypes = [voidp, voidp, voidp, i, i, C.c_float]
     L.vh_launch_linear_h2.argtypes = [voidp, voidp, voidp, C.c_float, voidp, voidp, i, i, i, i, voidp]
     L.vh_launch_softmax.argtypes = [voidp, voidp, voidp, i, i]
+    L.vh_launch_split3_rows.argtypes = [voidp, voidp, voidp, i, i]
+    L.vh_launch_merge3_rows.argtypes = [voidp, voidp, voidp, i, i]
+    L.vh_launch_layer_norm_p3.argtypes = [voidp] + [voidp] * 4 + [i, i, C.c_long, C.c_double]
+    L.vh_launch_attention_p3.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_linear_p3.argtypes = [voidp, voidp, i, voidp, voidp, voidp, i, i, i, i, voidp]
     L.vit_config_preset.argtypes = [C.POINTER(VitConfig), C.c_char_p]
     L.vit_config_tokens.argtypes = [C.POINTER(VitConfig)]
     L.vit_config_num_tensors.argtypes = [C.POINTER(VitConfig)]
