@@ -13,12 +13,17 @@ per-GPU work is fixed as N grows ("weak").
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fc1
-GEMM, gemm_f32_kernel<A_ROWS, EPI_GELU>): algorithmic FLOPs per launch divided by
+GEMM: gemm_p3_kernel<8,256,EPI_GELU,OUT_P3> plus its 128x128-tile launch for the last
+partial scheduling round, csrc/gemm_p3.hip): algorithmic FLOPs per launch divided by
 its mean launch duration, measured with HIP events recorded on the launch stream
 inside the timed region.  `cpu_baseline` is the reference's own ViT_seq.c
 (oracle/_ref, built in the build container) or, failing that, the oracle port,
-timed on this box's host cores on a bounded sample; its logits for image 0 are
-also used to report the parity of the GPU result in the same run.
+timed on this box's host cores on a bounded sample: first one image on one thread
+(the reference's own execution model, ViT_seq.c:433), then one image per usable
+core; the images are chosen to straddle the GPU path's tile and launch boundaries
+and their logits give the parity of the GPU result in the same run.
+`end_to_end` is the host-pointer entry vit_hip_forward (separately allocated host
+images in, probabilities out, PCIe included) -- reported beside `value`, never as it.
 """
 from __future__ import annotations
 
@@ -56,35 +61,77 @@ def model_flops(cfg, tokens: int) -> dict[str, float]:
     }
 
 
-def cpu_baseline(n_procs: int):
-    """Time the CPU path on this box: one synthetic image per process, n_procs at once.
-    Returns (dict for the JSON line, logits of image 0 or None)."""
+# Images whose CPU logits are compared with the GPU's: first / last of the batch, both sides of a
+# 256-row tile edge inside an image pair (rows 255|256 belong to image 1), and both sides of the
+# hand-over from the 256x256-tile launch to the 128x128-tile launch (row 98 304 = image 499 at batch 512).
+PARITY_IMAGES = [0, 1, 255, 498, 499, 511]
+
+
+def host_cpu_info() -> dict:
+    """What this process may use of the box: logical CPUs, affinity, cgroup quota, model name."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    if quota:
+        usable = min(usable, quota)
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "usable_cores": usable}
+
+
+def cpu_baseline(batch: int, n_procs: int):
+    """Time the CPU path on this box.  Returns (dict for the JSON line, {image index: logits})."""
     harness = ROOT / "oracle" / "_ref" / "ref_harness"
+    info = host_cpu_info()
+    n_procs = n_procs or info["usable_cores"]
+    # the parity images first, then as many more images as there are cores to fill
+    want = [i for i in PARITY_IMAGES if i < batch]
+    images = (want + [i for i in range(batch) if i not in want])[:max(n_procs, 1) + 1]   # 1 alone, then n_procs at once
     with tempfile.TemporaryDirectory() as td:
         if harness.exists() and os.access(harness, os.X_OK):
-            t0 = time.perf_counter()
-            procs = []
-            for i in range(n_procs):
-                out = Path(td) / f"img{i}.bin"
-                procs.append(subprocess.Popen([str(harness), "full", str(i), "1", "0", str(out)],
-                                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
-            ok = all(p.wait(timeout=600) == 0 for p in procs)
-            dt = time.perf_counter() - t0
-            if ok:
-                from oracle.oracle import read_records
-                logits0 = read_records(Path(td) / "img0.bin")["logits"]
-                return ({"value": n_procs / dt, "unit": "images/sec", "cores": n_procs, "kind": "reference",
-                         "sample": f"{n_procs} synthetic image(s), one per process, through the reference's "
-                                   f"own ViT_seq.c (oracle/_ref), {dt:.1f} s wall"}, logits0)
-        # fall back to the oracle port in worker processes (still only a baseline / checker)
+            from oracle.oracle import read_records
+
+            def run(indices):
+                t0 = time.perf_counter()
+                procs = [subprocess.Popen([str(harness), "full", str(i), "1", "0", str(Path(td) / f"img{i}.bin")],
+                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in indices]
+                ok = all(p.wait(timeout=900) == 0 for p in procs)
+                return ok, time.perf_counter() - t0
+
+            ok1, dt1 = run(images[:1])                 # one thread, one image: the reference's own model
+            okn, dtn = run(images[1:]) if len(images) > 1 else (True, 0.0)
+            if ok1 and okn:
+                logits = {i: read_records(Path(td) / f"img{i}.bin")["logits"] for i in images}
+                n_all = max(len(images) - 1, 1)
+                return ({"value": (n_all / dtn) if len(images) > 1 else 1.0 / dt1, "unit": "images/sec",
+                         "cores": n_all if len(images) > 1 else 1, "kind": "reference",
+                         "single_thread": {"value": 1.0 / dt1, "unit": "images/sec", "cores": 1,
+                                           "seconds_per_image": round(dt1, 2)},
+                         **info,
+                         "sample": f"the reference's own ViT_seq.c (oracle/_ref): 1 synthetic image on one thread "
+                                   f"({dt1:.1f} s), then {n_all} images, one per process, at once ({dtn:.1f} s wall)"},
+                        logits)
+        # fall back to the oracle port (still only a baseline / checker)
         from oracle.oracle import Oracle
         orc = Oracle("vit_b_16")
         w = orc.synth_weights(0)
         t0 = time.perf_counter()
         logits0, _, _ = orc.forward(orc.synth_image(0), w)
         dt = time.perf_counter() - t0
-        return ({"value": 1.0 / dt, "unit": "images/sec", "cores": 1, "kind": "port",
-                 "sample": f"1 synthetic image through oracle/vit_seq_port.c, {dt:.1f} s wall"}, logits0)
+        return ({"value": 1.0 / dt, "unit": "images/sec", "cores": 1, "kind": "port", **info,
+                 "sample": f"1 synthetic image through oracle/vit_seq_port.c on one thread, {dt:.1f} s wall"},
+                {0: logits0})
 
 
 def main() -> None:
@@ -97,6 +144,7 @@ def main() -> None:
                     help="f32 = the parity path (default, what `value` is quoted on); bf16 = bf16-operand GEMMs "
                          "(BASELINE config 3; logits ~1e-2 from ViT_seq.c, so never the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--model", choices=["vit_b_16", "vit_l_16", "vit_h_14"], default="vit_b_16",
                     help="vit_b_16 is BASELINE.json's metric; the others are the parity-test shapes, timed for DESIGN.md")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (0 = auto)")
@@ -146,9 +194,13 @@ def main() -> None:
     use_rccl = comm is not None and comm.backend == "nccl"
     if use_rccl:
         # logits land in a torch tensor so RCCL can gather them; launch on torch's stream
+        # on a torch side stream (a non-zero handle: 0 would mean "the context's own stream" to the
+        # library, which RCCL does not order against); the gather is enqueued on the same stream
         t_logits = torch.empty(B, NC, device="cuda", dtype=torch.float32)
         d_logits_ptr = t_logits.data_ptr()
-        stream = torch.cuda.current_stream().cuda_stream
+        t_stream = torch.cuda.Stream()
+        stream = t_stream.cuda_stream
+        assert stream != 0
     else:
         d_logits = pkg.DeviceBuffer(B * NC)
         d_logits_ptr = d_logits.ptr
@@ -158,7 +210,8 @@ def main() -> None:
     def step():
         model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
         if use_rccl:
-            gathered[0] = comm.gather_rows(t_logits)
+            with torch.cuda.stream(t_stream):
+                gathered[0] = comm.gather_rows(t_logits)
         elif comm is not None:   # gloo rehearsal: through host memory
             gathered[0] = comm.gather_rows(torch.from_numpy(d_logits.to_numpy((B, NC))))
 
@@ -234,6 +287,31 @@ def main() -> None:
         model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
         pkg.binding.check(L.vh_device_sync(), "sync")
 
+    # End-to-end through the host-pointer entry (what ViT_opencl() runs): separately allocated host
+    # images in, probabilities out, PCIe included.  Reported beside `value`, never as it.
+    e2e = None
+    if comm is None and args.dtype == "f32" and args.model == "vit_b_16" and not args.no_end_to_end:
+        import ctypes as C
+        host = pkg.synth_images(cfg, 0, min(B, 512))
+        n_e2e = 8 * B
+        arr = (pkg.binding.ImageData * n_e2e)()
+        for i in range(n_e2e):
+            arr[i].n, arr[i].c, arr[i].h, arr[i].w = n_e2e, cfg.in_chans, cfg.img_size, cfg.img_size
+            arr[i].data = pkg.binding.fptr(host[i % host.shape[0]])
+        h_probs = np.empty((n_e2e, NC), dtype=np.float32)
+        prow = (pkg.binding.f32p * n_e2e)(*[pkg.binding.fptr(h_probs[i]) for i in range(n_e2e)])
+        pkg.binding.check(L.vit_hip_forward(model.ctx, arr, min(n_e2e, 2 * B), None, prow), "vit_hip_forward")   # warm-up
+        t0e = time.perf_counter()
+        pkg.binding.check(L.vit_hip_forward(model.ctx, arr, n_e2e, None, prow), "vit_hip_forward")
+        dte = time.perf_counter() - t0e
+        e2e = {"value": round(n_e2e / dte, 1), "unit": "images/sec", "images": n_e2e, "chunk": B,
+               "what": "vit_hip_forward: host images (separately allocated, pageable) -> pinned staging -> H2D -> forward -> "
+                       "probabilities D2H -> caller's rows; double-buffered over chunks",
+               "prob_sum_image0": float(h_probs[0].sum())}
+        # restore the device-resident outputs the checks below read
+        model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
+        pkg.binding.check(L.vh_device_sync(), "sync")
+
     if rank == 0:
         flops = model_flops(cfg, tokens)
         total_flops = sum(flops.values())
@@ -251,8 +329,12 @@ def main() -> None:
                 per_launch = flops[name] * B / (cnt // PROF_STEPS)
                 entry["tflops"] = round(per_launch / (avg_ms * 1e-3) / 1e12, 2)
             elif name == "layer_norm":
-                # algorithmic bytes: read + write one [rows][E] fp32 tensor (final LN is tiny)
-                bytes_per = 2.0 * B * tokens * cfg.embed_dim * 4
+                # algorithmic bytes: read one [rows][E] fp32 tensor, write it as fp32 or (pre-split path) as three
+                # bf16 parts = 6 bytes per value (the final LN is tiny)
+                p3_ln = args.dtype == "f32" and os.environ.get("VIT_HIP_P3", "1") != "0" and \
+                    not os.environ.get("VIT_HIP_GEMM_FP32", "s").startswith("n")
+                bytes_per = B * tokens * cfg.embed_dim * (4.0 + (6.0 if p3_ln else 4.0 if args.dtype in ("f32", "f32_fp16x2") else
+                                                                 2.0 if args.dtype == "bf16" else 1.0))
                 entry["gbs"] = round(bytes_per / (avg_ms * 1e-3) / 1e9, 1)
                 entry["frac_hbm_peak"] = round(entry["gbs"] / PEAK_HBM_GBS, 4)
             kernels[name] = entry
@@ -274,27 +356,36 @@ def main() -> None:
                                                 "product block; the native fp32 MFMA peak is 157.3")
         # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes
         # (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); bench.py cannot collect PMCs itself.
+        p3 = args.dtype == "f32" and not native and os.environ.get("VIT_HIP_P3", "1") != "0"
         traffic, traffic_src = None, None
-        pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if pmc.exists() and B == 512 and args.model == "vit_b_16" and args.dtype == "f32" and not native and "gemm_mf16_kernel" in pmc.read_text():
+        pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
+        if pmc.exists() and B == 512 and args.model == "vit_b_16" and p3:
             traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, B=512)"
-        roofline = {"bound": "mfma",
-                    "kernel": "%s fc1 GEMM (M=%d N=%d K=%d); %s" %
-                    ("gemm_f32_kernel<...EPI_GELU...>" if native or args.dtype != "f32" and False else
-                     "gemm_mf16_kernel<Tile<256,256,4,2>,A_ROWS,EPI_GELU,...> (+ its Tile<128,128,4,1> launch for the last partial round)",
-                     B * tokens, cfg.mlp_hidden, cfg.embed_dim,
-                     "native fp32 MFMA (v_mfma_f32_32x32x2_f32), Tile<256,256,4,4>" if native else
+            traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, B=512)"
+        rows = B * tokens
+        if p3:     # operands and result as three bf16 parts: 6 bytes per value
+            alg_bytes = (rows * (cfg.embed_dim + cfg.mlp_hidden) + cfg.mlp_hidden * cfg.embed_dim) * 6
+            kname = ("gemm_p3_kernel<8,256,EPI_GELU,OUT_P3> (+ its gemm_p3_kernel<4,128,...> launch for the last partial "
+                     "scheduling round), csrc/gemm_p3.hip")
+            arith = ("both operands pre-split exactly into 3 bf16 parts by their producers (weights at context creation, "
+                     "activations by LayerNorm), 6 x v_mfma_f32_16x16x32_bf16 per block, no split arithmetic in the K loop; "
+                     "the GELU output is written pre-split for fc2")
+        else:
+            alg_bytes = (rows * (cfg.embed_dim + cfg.mlp_hidden) + cfg.mlp_hidden * cfg.embed_dim) * 4
+            kname = "gemm_f32_kernel<...EPI_GELU...>" if native else "gemm_mf16_kernel<...,EPI_GELU,...> (csrc/gemm_mfma.hip)"
+            arith = ("native fp32 MFMA (v_mfma_f32_32x32x2_f32), Tile<256,256,4,4>" if native else
                      "bf16 operands on v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16" else
                      "e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8" if args.dtype == "fp8" else
                      "fp32 operands as two fp16 parts, 3 x v_mfma_f32_16x16x32_f16 per block (not exact)"
                      if args.dtype == "f32_fp16x2" else
-                     "exact 3-way bf16 split of fp32 operands (weights pre-split), 6 x v_mfma_f32_16x16x32_bf16 per block"),
+                     "exact 3-way bf16 split of fp32 operands inside the K loop (weights pre-split), 6 x v_mfma_f32_16x16x32_bf16 per block")
+        roofline = {"bound": "mfma",
+                    "kernel": "%s: fc1 GEMM (M=%d N=%d K=%d); %s" % (kname, rows, cfg.mlp_hidden, cfg.embed_dim, arith),
                     "peak_basis": peak_note,
                     "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(achieved / peak_tf, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
-                    "algorithmic_bytes": (B * tokens * (cfg.embed_dim + cfg.mlp_hidden) + cfg.mlp_hidden * cfg.embed_dim) * 4}
+                    "algorithmic_bytes": alg_bytes}
 
         # sanity of what was computed + parity against the CPU path in the same run
         if comm is not None:
@@ -328,16 +419,24 @@ def main() -> None:
             out["bf16_gemm_mode"] = bf16_leg
         if emu_leg is not None:
             out["fp32_fp16x2_emulation_mode"] = emu_leg
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline and args.model == "vit_b_16":
-            nproc = args.cpu_procs or max(1, min(os.cpu_count() or 1, 16))
-            base, ref_logits = cpu_baseline(nproc)
+            base, ref_logits = cpu_baseline(B, args.cpu_procs)
             out["cpu_baseline"] = base
-            if ref_logits is not None:
-                out["parity"] = {"max_abs_dlogit_vs_ViT_seq": float(np.abs(logits0 - ref_logits).max()),
-                                 "argmax_equal": bool(int(logits0.argmax()) == int(ref_logits.argmax())),
-                                 "tolerance": 1e-4, "image": 0}
-                if emu_leg is not None:
-                    emu_leg["max_abs_dlogit_vs_ViT_seq"] = float(np.abs(emu_logits0 - ref_logits).max())
+            if ref_logits:
+                gl = d_logits.to_numpy((B, NC))
+                imgs = sorted(ref_logits)
+                dl = {i: float(np.abs(gl[i] - ref_logits[i]).max()) for i in imgs}
+                out["parity"] = {"max_abs_dlogit_vs_ViT_seq": max(dl.values()),
+                                 "argmax_equal": bool(all(int(gl[i].argmax()) == int(ref_logits[i].argmax()) for i in imgs)),
+                                 "tolerance": 1e-4, "images": imgs,
+                                 "per_image": {str(i): dl[i] for i in imgs if i in PARITY_IMAGES},
+                                 "note": "images 0/1, 255, 498/499 and 511 sit on the GPU path's tile and launch boundaries "
+                                         "(row 98 304, where the 256x256-tile launch hands over to the 128x128-tile launch, "
+                                         "is in image 499)"}
+                if emu_leg is not None and 0 in ref_logits:
+                    emu_leg["max_abs_dlogit_vs_ViT_seq"] = float(np.abs(emu_logits0 - ref_logits[0]).max())
         out["checks"] = {"logits_finite": bool(np.isfinite(logits0).all()),
                          "prob_sum_image0": float(probs0.sum())}
         print(json.dumps(out), flush=True)

@@ -21,6 +21,7 @@
 #include "ViT_opencl.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -392,8 +393,9 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
          * bf16 split (csrc/gemm_p3.hip), 6 bytes per value; VIT_HIP_P3=0 keeps fp32 activations and
          * the in-loop split (csrc/gemm_mfma.hip) */
         const char *env_p3 = getenv("VIT_HIP_P3");
+        const char *env_native = getenv("VIT_HIP_GEMM_FP32");   /* "native": the fp32 matrix instruction (gemm_mfma.hip) */
         ctx->use_p3 = ctx->w3_slab && precision == VIT_PRECISION_F32 && !(env_p3 && env_p3[0] == '0') &&
-                      rows * 64 <= 0xffffffffull;
+                      !(env_native && env_native[0] == 'n') && rows * 64 <= 0xffffffffull;
     }
     const size_t act = ctx->use_p3 ? 6 : sizeof(float);   /* bytes per GEMM-input value */
     TRY(vh_malloc((void **)&ctx->x, rows * E * sizeof(float)));
@@ -682,6 +684,57 @@ static void scatter_outputs(vit_hip_ctx *ctx, int slot, int first, int m, float 
             memcpy(probs[first + i], ctx->h_probs[slot] + (size_t)i * NC, NC * sizeof(float));
 }
 
+/* Gather of the separately allocated host images (Network.c:90) into one pinned staging slot, on
+ * several host threads: a single memcpy stream moves ~3 GB/s, which would cap the host-pointer path
+ * below the device-resident rate. */
+struct gather_job
+{
+    float *dst;
+    const ImageData *images;
+    int first, count;
+    size_t img;
+};
+
+static void *gather_worker(void *arg)
+{
+    const struct gather_job *j = (const struct gather_job *)arg;
+    for (int i = 0; i < j->count; ++i)
+        memcpy(j->dst + (size_t)(j->first + i) * j->img, j->images[j->first + i].data, j->img * sizeof(float));
+    return NULL;
+}
+
+static void gather_images(float *dst, const ImageData *images, int m, size_t img)
+{
+    enum { MAX_THREADS = 8 };
+    int nt = m / 16;
+    if (nt > MAX_THREADS)
+        nt = MAX_THREADS;
+    const char *env = getenv("VIT_HIP_GATHER_THREADS");
+    if (env && atoi(env) > 0)
+        nt = atoi(env) < MAX_THREADS ? atoi(env) : MAX_THREADS;
+    struct gather_job jobs[MAX_THREADS];
+    pthread_t tid[MAX_THREADS];
+    int started = 0;
+    if (nt < 2) {
+        struct gather_job all = {dst, images, 0, m, img};
+        gather_worker(&all);
+        return;
+    }
+    const int per = (m + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int first = t * per, count = first >= m ? 0 : (m - first < per ? m - first : per);
+        jobs[t] = (struct gather_job){dst, images, first, count, img};
+        if (count == 0)
+            break;
+        if (t == nt - 1 || pthread_create(&tid[started], NULL, gather_worker, &jobs[t]) != 0)
+            gather_worker(&jobs[t]);          /* the last share (or a failed create) runs here */
+        else
+            ++started;
+    }
+    for (int t = 0; t < started; ++t)
+        pthread_join(tid[t], NULL);
+}
+
 int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *logits, float **probs)
 {
     int rc = 0;
@@ -700,8 +753,7 @@ int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *log
         const int m = (n - first < ctx->max_batch) ? n - first : ctx->max_batch;
         const int s = k & 1;
         /* slot s was last used by chunk k-2, whose outputs were waited for below */
-        for (int i = 0; i < m; ++i)
-            memcpy(ctx->h_images[s] + (size_t)i * img, images[first + i].data, img * sizeof(float));
+        gather_images(ctx->h_images[s], images + first, m, img);
         if (k >= 2)
             TRY(vh_stream_wait_event(ctx->copy_stream, ctx->comp_done[s]));
         TRY(vh_h2d(ctx->d_images[s], ctx->h_images[s], (size_t)m * img * sizeof(float), ctx->copy_stream));
