@@ -114,6 +114,27 @@ int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *log
 int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float *d_logits,
                            float *d_probs, vh_stream_t stream);
 
+/* ---- several GPUs behind one call (the reference takes exactly one device, ViT_opencl.c:803) ----
+ * Batch shards only: images never interact (ViT_opencl.c:926), so n images are cut into n_devices
+ * contiguous shards (shard s = images [s*ceil(n/G), ...)); every device holds a full replica of the weights
+ * and is driven by its own host thread, context and stream; each thread writes its shard's outputs
+ * directly into the caller's `logits` / `probs`, so no collective is needed inside one process.
+ * `ViT_opencl` takes this path when $VIT_HIP_DEVICES names more than one device ("all" or "0,1,...").
+ * A device id may repeat (two replicas on one GPU: used by the single-GPU tests). */
+typedef struct vit_hip_multi vit_hip_multi;
+int vit_hip_create_multi(vit_hip_multi **out, const vit_config *cfg, const Network *networks, int n_tensors,
+                         const int *devices, int n_devices, int max_batch_per_device, int precision);
+int vit_hip_forward_multi(vit_hip_multi *m, const ImageData *images, int n, float *logits, float **probs);
+void vit_hip_destroy_multi(vit_hip_multi *m);
+int vit_hip_multi_devices(const vit_hip_multi *m);
+vit_hip_ctx *vit_hip_multi_ctx(const vit_hip_multi *m, int i);
+/* The sharding primitives on their own (host logic, no device needed): shard `shard` of [0, total) cut
+ * into n_shards contiguous pieces of ceil(total / n_shards); and a runner that calls
+ * fn(arg, shard, lo, hi) for every non-empty shard, each on its own host thread, and returns 0 or the
+ * first failing shard's status. */
+void vit_shard_range(int total, int shard, int n_shards, int *lo, int *hi);
+int vit_shard_run(int total, int n_shards, int (*fn)(void *arg, int shard, int lo, int hi), void *arg);
+
 /* Introspection for tests / profiling. */
 const vit_config *vit_hip_config(const vit_hip_ctx *ctx);
 vh_stream_t vit_hip_stream(const vit_hip_ctx *ctx);

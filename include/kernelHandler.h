@@ -49,6 +49,7 @@ int vh_device_count(void);                 /* number of visible HIP devices (0 i
 int vh_init(int device);                   /* select `device`; fails unless it is a gfx950 part */
 const char *vh_last_error(void);           /* text of the last failure on this thread ("" if none) */
 const char *vh_device_name(void);          /* e.g. "AMD Instinct MI355X (gfx950, 256 CUs)" */
+int vh_set_device(int device);             /* make `device` current for the calling thread (after vh_init) */
 
 int vh_stream_create(vh_stream_t *out);
 int vh_stream_destroy(vh_stream_t s);

@@ -18,6 +18,10 @@ Fixtures (inputs are regenerated from seeds, never stored):
   b16_answer_result.txt  Main.c-format result lines ("[i] label: L / prob: P")
   b16_full_rounded.npz / b16_answer_result_rounded.txt  the same with weights rounded to 1e-6
                   as the reference loader delivers them from disk (Network.c:208-211)
+  b16_answer_result_100_rounded.txt  (`make_golden.py answers100`) 100 result lines -- comparator.c's
+                  IMAGE_COUNT (comparator.c:9) -- for synthetic images 0..99 on rounded weights, written
+                  with Main.c's own arg-max loop (Main.c:59-71: pred_idx is NOT reset per image and class 0
+                  is never visited, so the line is what the reference's Main.c would print around ViT_seq)
 """
 from __future__ import annotations
 
@@ -46,7 +50,45 @@ def summarize(a: np.ndarray) -> dict[str, np.ndarray]:
     }
 
 
+def main_c_lines(probs: np.ndarray) -> list[str]:
+    """The result lines exactly as Main.c:59-72 produces them from `probabilities`."""
+    lines, pred = [], 0
+    for i in range(probs.shape[0]):
+        for j in range(1, probs.shape[1]):          # Main.c:62: j starts at 1; pred carries over (Main.c:59)
+            if probs[i][j] > probs[i][pred]:
+                pred = j
+        lines.append("[%d] label: %d / prob: %.6f\n" % (i, pred, probs[i][pred]))
+    return lines
+
+
+def answers100(workers: int = 8) -> None:
+    """100 images through the reference's ViT_seq.c on 1e-6-rounded weights, `workers` processes at a time."""
+    import subprocess
+    orc.build()
+    if not orc.have_reference():
+        sys.exit("oracle/_ref/ref_harness missing: run in the build container (needs /root/reference)")
+    n = 100
+    probs = np.empty((n, 1000), dtype=np.float32)
+    with tempfile.TemporaryDirectory() as td:
+        for lo in range(0, n, workers):
+            idx = list(range(lo, min(n, lo + workers)))
+            procs = [subprocess.Popen([str(orc.REF_HARNESS), "full_rounded", str(i), "1", "0", str(Path(td) / f"{i}.bin")],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in idx]
+            assert all(p.wait() == 0 for p in procs)
+            for i in idx:
+                probs[i] = orc.read_records(Path(td) / f"{i}.bin")["probs"]
+            print("images", idx[0], "..", idx[-1], "done", flush=True)
+    (GOLD / "b16_answer_result_100_rounded.txt").write_text("".join(main_c_lines(probs)))
+    # cross-check against the 4-image rounded fixture
+    small = np.load(GOLD / "b16_full_rounded.npz")["probs"]
+    assert np.array_equal(small, probs[:4]), "100-image run disagrees with b16_full_rounded.npz"
+    print("wrote b16_answer_result_100_rounded.txt; labels:", sorted(set(int(l.split()[2]) for l in main_c_lines(probs))))
+
+
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "answers100":
+        answers100()
+        return
     orc.build()
     if not orc.have_reference():
         sys.exit("oracle/_ref/ref_harness missing: run in the build container (needs /root/reference)")

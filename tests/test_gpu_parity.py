@@ -393,6 +393,38 @@ def test_device_resident_path_and_full_size_properties(pkg, device, weights):
     m.close()
 
 
+def test_multi_device_entry_is_bit_identical_to_one_context(pkg, device, weights, golden_full):
+    """vit_hip_create_multi / vit_hip_forward_multi (one host thread, context and stream per
+    device, contiguous shards, outputs scattered straight into the caller's arrays).  This box has one
+    GPU, so: (i) devices = [0] must equal the single-context path bit for bit; (ii) devices = [0, 0] --
+    two replicas and two host threads on the same card -- splits 5 images 3 + 2 and must give the same
+    bits again (an image's result does not depend on its shard); (iii) the drop-in ViT_opencl with
+    $VIT_HIP_DEVICES=0,0 fills every probability row."""
+    import os
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 0, 5)
+    one = pkg.ViTHip(cfg, weights, device=0, max_batch=3)
+    base, base_p = one.forward(imgs)
+    one.close()
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        m = pkg.ViTHipMulti(cfg, weights, devs, max_batch_per_device=2)
+        logits, probs = m.forward(imgs)
+        m.close()
+        assert np.array_equal(logits, base) and np.array_equal(probs, base_p), devs
+    assert np.abs(base[:4] - golden_full["logits"]).max() <= LOGIT_TOL
+    b, L = pkg.binding, pkg.lib()
+    out = np.full((5, 1000), -1.0, dtype=np.float32)
+    rows = (b.f32p * 5)(*[b.fptr(out[i]) for i in range(5)])
+    os.environ["VIT_HIP_DEVICES"] = "0,0"
+    try:
+        L.ViT_opencl(b.image_array(imgs), b.networks(weights), rows)
+    finally:
+        del os.environ["VIT_HIP_DEVICES"]
+    assert np.array_equal(out, base_p)
+    with pytest.raises(pkg.VitHipError):
+        pkg.ViTHipMulti(cfg, weights, [0, 99], max_batch_per_device=2)      # no such device: loud failure
+
+
 def test_torch_interop_shares_one_hip_runtime(pkg, device, weights, golden_full):
     """bench.py hands torch-allocated HBM to the library (torch.distributed needs
     the logits in a torch tensor for the RCCL gather)."""
@@ -426,6 +458,21 @@ def test_vit_l16_one_image_vs_oracle(pkg, device):
     assert np.abs(logits[1] - want_logits).max() <= LOGIT_TOL
     assert int(logits[1].argmax()) == int(want_logits.argmax())
     assert np.abs(probs[1] - want_probs).max() <= 1e-6
+    # BASELINE config 4 in ITS precision: ViT-L/16 with bf16 GEMM operands (fp32 accumulation, residual
+    # stream, norms and attention statistics).  Stated tolerance: class logits within 6e-2 of the CPU
+    # port (24 layers of 8-bit operands; B/16's 12 layers are held to 4e-2), probabilities within 3e-4,
+    # arg-max equal where the port's top-2 margin exceeds twice the tolerance.  "parity unpinned".
+    m16 = pkg.ViTHip(cfg, weights, device=0, max_batch=2, precision="bf16")
+    l16, p16 = m16.forward(imgs)
+    m16.close()
+    d16 = float(np.abs(l16[1] - want_logits).max())
+    print("ViT-L/16 bf16 mode: max |dlogit| vs port", d16, "vs fp32 path", float(np.abs(l16 - logits).max()))
+    assert np.isfinite(l16).all() and d16 <= 6e-2
+    assert np.abs(p16[1] - want_probs).max() <= 3e-4
+    srt = np.sort(want_logits)
+    if srt[-1] - srt[-2] > 1.2e-1:
+        assert int(l16[1].argmax()) == int(want_logits.argmax())
+    assert np.abs(l16[0] - logits[0]).max() <= 6e-2          # image 0: against the fp32 path (itself checked above)
 
 
 def test_vit_h14_layers_vs_oracle(pkg, device):
@@ -456,6 +503,25 @@ def test_vit_h14_layers_vs_oracle(pkg, device):
     l16, _ = m16.forward(imgs)
     m16.close()
     assert np.isfinite(l16).all() and np.abs(l16 - logits).max() <= 8e-2
+    # BASELINE config 5 in ITS precision: ViT-H/14 with e4m3 GEMM operands (per-row weight scales,
+    # per-tensor activation scales calibrated on OTHER images), against the fp32 path of this same
+    # test (itself checked against the port after 3 layers above).  Same statement of tolerance as the
+    # B/16 fp8 test: relative L2 error of the logit vector, and top-1 where the margin is clear.
+    # "parity unpinned" (the reference has no H/14 and no fp8).
+    m8 = pkg.ViTHip(cfg, weights, device=0, max_batch=2, precision="fp8")
+    with pytest.raises(pkg.VitHipError):
+        m8.forward(imgs[:1])                                   # uncalibrated: refuses
+    scales = m8.calibrate_fp8(pkg.synth_images(cfg, 100, 4))
+    assert scales.shape == (cfg.depth, 4) and (scales > 0).all()
+    l8, p8 = m8.forward(imgs)
+    m8.close()
+    rel = np.linalg.norm(l8 - logits, axis=1) / np.linalg.norm(logits - logits.mean(axis=1, keepdims=True), axis=1)
+    print("ViT-H/14 fp8 mode: relative L2 logit error per image:", rel, "max |dlogit|", float(np.abs(l8 - logits).max()))
+    assert np.isfinite(l8).all() and np.abs(p8.sum(axis=1) - 1).max() < 1e-5
+    assert rel.max() <= 0.25
+    top2 = np.sort(logits, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 4 * np.abs(l8 - logits).max(axis=1)
+    assert (l8.argmax(1) == logits.argmax(1))[clear].all()
 
 
 # torchvision state-dict key of tensor idx (reference file names: Network/Weight_<idx>_<key>.bin)
@@ -475,8 +541,9 @@ def test_c_driver_over_files_matches_reference_flow(pkg, device, weights, tmp_pa
     """The whole drop-in flow from C, no Python in the process: a synthetic ./Data +
     ./Network tree in the reference's on-disk formats -> load_image_data / load_weights
     (with the 1e-6 rounding, Network.c:208-211) -> ViT_opencl -> result file in Main.c's
-    format -> comparator-style check against the answer file produced by the reference's
-    own ViT_seq.c on equally rounded weights (oracle/make_golden.py, full_rounded)."""
+    format, checked against the outputs of the reference's own ViT_seq.c on equally rounded
+    weights (oracle/make_golden.py, full_rounded).  The reference's own Main.c + comparator.c
+    run in test_reference_main_and_comparator_drop_in_unchanged."""
     import shutil
     import subprocess
     from pathlib import Path
@@ -492,10 +559,9 @@ def test_c_driver_over_files_matches_reference_flow(pkg, device, weights, tmp_pa
     for idx, w in enumerate(weights):
         assert L.vit_write_weight_file(str(tmp_path / "Network").encode(), idx, _tensor_name(idx).encode(),
                                        b.fptr(w), w.size) == 0
-    shutil.copy(root / "tests" / "golden" / "b16_answer_result_rounded.txt", tmp_path / "Data" / "answer_result.txt")
     r = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     print(r.stdout[-600:], r.stderr[-600:])
-    assert r.returncode == 0, "comparator reported differences"
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
     # the same flow with the projections emulated on fp16 pairs ($VIT_HIP_PRECISION=fp16x2): same verdict
     import os
     r2 = subprocess.run([str(exe), "./Data/input-100.bin", "./Network", "./Data/fp16x2_result.txt"], cwd=tmp_path,
@@ -511,6 +577,46 @@ def test_c_driver_over_files_matches_reference_flow(pkg, device, weights, tmp_pa
         prob = float(line.split("prob:")[1])
         assert label == int(gold["probs"][i].argmax())
         assert abs(prob - float(gold["probs"][i].max())) <= 2e-6
+
+
+def test_reference_main_and_comparator_drop_in_unchanged(pkg, device, weights, tmp_path):
+    """North star: "Main.c and comparator.c drop in unchanged".  oracle/_ref/ref_main is the reference's
+    OWN Main.c + comparator.c, compiled where they lie (oracle/Makefile; nothing copied, their own
+    headers, MSVC CRT names from tests/compat/msvc_compat.h) and linked against libvit_hip.so.  Here it
+    runs on a synthetic 100-image ./Data + 152-file ./Network tree in the reference's on-disk formats;
+    ./Data/answer_result.txt holds what the reference's own ViT_seq.c + Main.c print for the same files
+    (tests/golden/b16_answer_result_100_rounded.txt, oracle/make_golden.py answers100).  Pass = the
+    comparator's success branch (Main.c:76-80: "good"), i.e. 100 labels equal, 100 probabilities within 0.01
+    (comparator.c:74-86) -- and, stricter, every printed probability within 2e-6 of the golden line."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    L, b = pkg.lib(), pkg.binding
+    root = Path(__file__).resolve().parent.parent
+    exe = root / "oracle" / "_ref" / "ref_main"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/ref_main not built (needs the reference tree in the build container)")
+    (tmp_path / "Data").mkdir()
+    (tmp_path / "Network").mkdir()
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 0, 100)
+    assert L.vit_write_image_file(str(tmp_path / "Data" / "input-100.bin").encode(), b.image_array(imgs), 100) == 0
+    for idx, w in enumerate(weights):
+        assert L.vit_write_weight_file(str(tmp_path / "Network").encode(), idx, _tensor_name(idx).encode(),
+                                       b.fptr(w), w.size) == 0
+    gold = root / "tests" / "golden" / "b16_answer_result_100_rounded.txt"
+    shutil.copy(gold, tmp_path / "Data" / "answer_result.txt")
+    r = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, timeout=600)
+    out = r.stdout.decode("utf-8", "replace")
+    print(out[-800:], r.stderr.decode("utf-8", "replace")[-400:])
+    assert r.returncode == 0
+    assert "good" in out and "bad1" not in out and "bad2" not in out        # Main.c:76-90
+    got = (tmp_path / "Data" / "opencl_result.txt").read_text().splitlines()
+    want = gold.read_text().splitlines()
+    assert len(got) == len(want) == 100
+    for g, w_ in zip(got, want):
+        assert g.split("/")[0] == w_.split("/")[0], (g, w_)                   # "[i] label: L"
+        assert abs(float(g.split("prob:")[1]) - float(w_.split("prob:")[1])) <= 2e-6, (g, w_)
 
 
 # ---- bf16-operand GEMM mode (BASELINE config 3) -------------------------------------

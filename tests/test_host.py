@@ -186,6 +186,40 @@ def test_shard_range_covers_batch_exactly_once(pkg):
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= (total + world - 1) // world
 
 
+def test_shard_runner_covers_the_batch_once_and_reports_failures(pkg):
+    """The in-library multi-GPU driver without a GPU: vit_shard_range / vit_shard_run (what
+    vit_hip_forward_multi is made of) with a stub "forward" that records its shard -- every image is
+    visited exactly once, shards are contiguous and in device order, each non-empty shard runs on its own
+    host thread, empty shards are skipped, and a failing shard's status comes back."""
+    import threading
+    L, b = pkg.lib(), pkg.binding
+    for total in (0, 1, 5, 64, 100, 513):
+        for shards in (1, 2, 3, 8):
+            spans = []
+            for s_ in range(shards):
+                lo, hi = C.c_int(), C.c_int()
+                L.vit_shard_range(total, s_, shards, C.byref(lo), C.byref(hi))
+                spans.append((lo.value, hi.value))
+                assert (lo.value, hi.value) == b.shard_range(total, s_, shards)     # same rule as the per-process form
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(shards - 1))
+            seen = np.zeros(max(total, 1), dtype=np.int32)
+            calls, lock = [], threading.Lock()
+
+            def stub(arg, shard, lo, hi):
+                with lock:
+                    calls.append((shard, lo, hi, threading.get_ident()))
+                seen[lo:hi] += 1
+                return 0
+            assert L.vit_shard_run(total, shards, b.SHARD_FN(stub), None) == 0
+            assert (seen[:total] == 1).all()
+            assert sorted(c[:3] for c in calls) == [(s_, lo, hi) for s_, (lo, hi) in enumerate(spans) if hi > lo]
+            assert len({c[3] for c in calls}) == len(calls)                            # one host thread per shard
+    fail = b.SHARD_FN(lambda arg, shard, lo, hi: 7 if shard == 2 else 0)
+    assert L.vit_shard_run(100, 4, fail, None) == 7
+    assert L.vit_shard_run(100, 0, fail, None) != 0 and L.vit_shard_run(-1, 2, fail, None) != 0
+
+
 def test_fp8_reference_round_trips_every_code():
     """tests/fp8_ref.py (the numpy statement of OCP e4m3 the GPU casts are checked against):
     every finite code survives dequantise -> quantise, ties go to the even code, overflow
@@ -198,6 +232,32 @@ def test_fp8_reference_round_trips_every_code():
     assert np.array_equal(back[keep] & 0x7f, codes[keep] & 0x7f) and np.array_equal(back[keep] >> 7, codes[keep] >> 7)
     assert fp8_ref.dequantize(fp8_ref.quantize(np.array([1e9, -1e9, 448.0, 464.0], np.float32))).tolist() == [448.0, -448.0, 448.0, 448.0]
     assert fp8_ref.quantize(np.array([1.0625, 1.1875, 2.0 ** -10], np.float32)).tolist() == [56, 58, 0]
+
+
+def test_fp8_reference_equals_torch_float8_e4m3fn():
+    """Pins tests/fp8_ref.py (builder-authored) to an independent implementation of OCP e4m3: PyTorch's
+    float8_e4m3fn cast on a million values (all magnitudes from subnormal to beyond 448, exact ties
+    included) and every code's value.  torch saturates nothing (values beyond 448 become NaN), so the
+    comparison is on |x| <= 448; the saturation rule is checked in the test above."""
+    torch = pytest.importorskip("torch")
+    import fp8_ref
+    rng = np.random.default_rng(7)
+    x = np.concatenate([
+        rng.standard_normal(400000).astype(np.float32) * np.float32(3.0),
+        (rng.random(300000).astype(np.float32) * np.float32(2.0) - np.float32(1.0)) * np.float32(448.0),
+        np.exp(rng.uniform(np.log(2.0 ** -12), np.log(448.0), 290000)).astype(np.float32) * rng.choice([-1.0, 1.0], 290000).astype(np.float32),
+        (fp8_ref.TABLE[:-1] + fp8_ref.TABLE[1:]).astype(np.float32) / np.float32(2.0),          # exact midpoints: ties
+        -((fp8_ref.TABLE[:-1] + fp8_ref.TABLE[1:]).astype(np.float32) / np.float32(2.0)),
+        fp8_ref.TABLE.astype(np.float32),
+        np.array([0.0, -0.0, 2.0 ** -10, 2.0 ** -9, 3 * 2.0 ** -11, 448.0, -448.0], np.float32)])
+    x = x[np.abs(x) <= 448.0]
+    want = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got = fp8_ref.quantize(x)
+    zero = (want & 0x7f) == 0                              # signed zeros: compare magnitudes only
+    assert np.array_equal(got[~zero], want[~zero]) and np.array_equal(got[zero] & 0x7f, want[zero] & 0x7f)
+    codes = np.array([c for c in range(256) if (c & 0x7f) != 0x7f], dtype=np.uint8)
+    assert np.array_equal(fp8_ref.dequantize(codes), torch.from_numpy(codes).view(torch.float8_e4m3fn).to(torch.float32).numpy())
+    assert x.size > 900000
 
 
 def test_result_file_and_strict_comparison(pkg, tmp_path):

@@ -7,6 +7,6 @@ Python identifier; load it with `__graft_entry__.load_package()`.
 """
 from .host import binding  # noqa: F401
 from .host.binding import (  # noqa: F401
-    DeviceBuffer, ViTHip, VitConfig, VitHipError, build_library, lib, preset, shard_range,
+    DeviceBuffer, ViTHip, ViTHipMulti, VitConfig, VitHipError, build_library, lib, preset, shard_range,
     synth_images, synth_weights,
 )

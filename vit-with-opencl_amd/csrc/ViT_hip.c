@@ -153,6 +153,7 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
 {
     if (!ctx)
         return;
+    vh_set_device(ctx->device);
     if (ctx->stream)
         vh_stream_sync(ctx->stream);
     prof_release(ctx);
@@ -435,6 +436,7 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     int rc = 0;
     if (!ctx || !d_images || n <= 0 || n > ctx->max_batch)
         return 1;
+    TRY(vh_set_device(ctx->device));   /* the current device is per host thread */
     const vit_config *c = &ctx->cfg;
     const int E = c->embed_dim, F = c->mlp_hidden, T = ctx->tokens, NC = c->num_classes;
     const int rows = n * T;
@@ -548,7 +550,10 @@ fail:
 /* Debug/test hook: copy the residual stream ([n*tokens][E]) to the host. */
 int vit_hip_read_tokens(vit_hip_ctx *ctx, int n, float *host_out)
 {
-    int rc = vh_d2h(host_out, ctx->x, (size_t)n * ctx->tokens * ctx->cfg.embed_dim * sizeof(float),
+    int rc = vh_set_device(ctx->device);
+    if (rc)
+        return rc;
+    rc = vh_d2h(host_out, ctx->x, (size_t)n * ctx->tokens * ctx->cfg.embed_dim * sizeof(float),
                     ctx->stream);
     return rc ? rc : vh_stream_sync(ctx->stream);
 }
@@ -561,6 +566,8 @@ int vit_hip_calibrate_fp8(vit_hip_ctx *ctx, const float *d_images, int n)
     int rc = 0;
     if (!ctx || ctx->precision != VIT_PRECISION_FP8_GEMM || !d_images || n <= 0)
         return 1;
+    if ((rc = vh_set_device(ctx->device)) != 0)
+        return rc;
     const vit_config *c = &ctx->cfg;
     const size_t per = (size_t)c->in_chans * c->img_size * c->img_size;
     const int n_scales = 4 * c->depth;
@@ -616,6 +623,7 @@ int vit_hip_profile_enable(vit_hip_ctx *ctx, int max_forwards)
     int rc = 0;
     if (!ctx)
         return 1;
+    TRY(vh_set_device(ctx->device));
     TRY(vh_stream_sync(ctx->stream));
     prof_release(ctx);
     if (max_forwards <= 0)
@@ -651,6 +659,7 @@ int vit_hip_profile_read(vit_hip_ctx *ctx, double ms_sum[VIT_OP_COUNT], long lau
     int rc = 0;
     if (!ctx || !ms_sum || !launches)
         return 1;
+    TRY(vh_set_device(ctx->device));
     for (int k = 0; k < VIT_OP_COUNT; ++k) {
         ms_sum[k] = 0.0;
         launches[k] = 0;
@@ -740,6 +749,7 @@ int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *log
     int rc = 0;
     if (!ctx || !images || n <= 0)
         return 1;
+    TRY(vh_set_device(ctx->device));
     const vit_config *c = &ctx->cfg;
     const size_t img = (size_t)c->in_chans * c->img_size * c->img_size;
     const size_t NC = (size_t)c->num_classes;
@@ -785,6 +795,196 @@ fail:
     return rc;
 }
 
+/* ---- several GPUs behind one call -------------------------------------------------
+ * Images never interact (the reference processes them strictly one at a time, ViT_opencl.c:926), so
+ * the batch is cut into contiguous shards, one per device; every device holds a full replica of the
+ * weights (346 MB for ViT-B/16) and is driven by its own host thread, context and stream.  A thread
+ * writes its shard's outputs straight into the caller's arrays, so inside one process the "gather of
+ * the class logits" is this scatter -- no collective.  (bench.py's one-process-per-GPU form gathers
+ * with RCCL instead.) */
+
+void vit_shard_range(int total, int shard, int n_shards, int *lo, int *hi)
+{
+    const int per = n_shards > 0 ? (total + n_shards - 1) / n_shards : total;
+    int a = shard * per, b;
+    if (a > total)
+        a = total;
+    b = a + per;
+    if (b > total)
+        b = total;
+    *lo = a;
+    *hi = b;
+}
+
+struct shard_job
+{
+    int (*fn)(void *arg, int shard, int lo, int hi);
+    void *arg;
+    int shard, lo, hi, rc;
+    char err[256];
+};
+
+static void *shard_worker(void *p)
+{
+    struct shard_job *j = (struct shard_job *)p;
+    j->rc = j->fn(j->arg, j->shard, j->lo, j->hi);
+    if (j->rc != 0)
+        snprintf(j->err, sizeof(j->err), "%s", vh_last_error());   /* the error text is per thread */
+    return NULL;
+}
+
+/* Run fn(arg, s, lo_s, hi_s) for the n_shards contiguous shards of [0, total), each non-empty shard
+ * on its own host thread (shard 0 on the caller's); returns 0 or the first failing shard's status. */
+int vit_shard_run(int total, int n_shards, int (*fn)(void *arg, int shard, int lo, int hi), void *arg)
+{
+    enum { MAX_SHARDS = 64 };
+    if (total < 0 || n_shards <= 0 || n_shards > MAX_SHARDS || !fn)
+        return 1;
+    struct shard_job jobs[MAX_SHARDS];
+    pthread_t tid[MAX_SHARDS];
+    int threaded[MAX_SHARDS];
+    for (int s = 0; s < n_shards; ++s) {
+        jobs[s] = (struct shard_job){fn, arg, s, 0, 0, 0, ""};
+        vit_shard_range(total, s, n_shards, &jobs[s].lo, &jobs[s].hi);
+        threaded[s] = 0;
+    }
+    for (int s = 1; s < n_shards; ++s)
+        if (jobs[s].hi > jobs[s].lo)
+            threaded[s] = pthread_create(&tid[s], NULL, shard_worker, &jobs[s]) == 0;
+    for (int s = 0; s < n_shards; ++s)
+        if (!threaded[s] && jobs[s].hi > jobs[s].lo)
+            shard_worker(&jobs[s]);               /* shard 0, and any shard whose thread could not start */
+    for (int s = 1; s < n_shards; ++s)
+        if (threaded[s])
+            pthread_join(tid[s], NULL);
+    for (int s = 0; s < n_shards; ++s)
+        if (jobs[s].rc != 0) {
+            fprintf(stderr, "vit_shard_run: shard %d [%d, %d) failed with status %d: %s\n", s, jobs[s].lo, jobs[s].hi,
+                    jobs[s].rc, jobs[s].err);
+            return jobs[s].rc;
+        }
+    return 0;
+}
+
+struct vit_hip_multi
+{
+    int n_devices;
+    vit_hip_ctx **ctx;
+    /* creation arguments, read by the per-device threads */
+    const vit_config *cfg;
+    const Network *networks;
+    const int *devices;
+    int n_tensors, max_batch, precision;
+    /* forward arguments */
+    const ImageData *images;
+    float *logits;
+    float **probs;
+};
+
+static int multi_create_one(void *arg, int shard, int lo, int hi)
+{
+    vit_hip_multi *m = (vit_hip_multi *)arg;
+    (void)lo;
+    (void)hi;
+    return vit_hip_create_ex(&m->ctx[shard], m->cfg, m->networks, m->n_tensors, m->devices[shard], m->max_batch,
+                             m->precision);
+}
+
+int vit_hip_create_multi(vit_hip_multi **out, const vit_config *cfg, const Network *networks, int n_tensors,
+                         const int *devices, int n_devices, int max_batch_per_device, int precision)
+{
+    if (!out || !cfg || !networks || !devices || n_devices <= 0 || n_devices > 64 || max_batch_per_device <= 0)
+        return 1;
+    *out = NULL;
+    vit_hip_multi *m = (vit_hip_multi *)calloc(1, sizeof(*m));
+    if (!m)
+        return 4;
+    m->ctx = (vit_hip_ctx **)calloc((size_t)n_devices, sizeof(*m->ctx));
+    int *devs = (int *)malloc(sizeof(int) * (size_t)n_devices);
+    if (!m->ctx || !devs) {
+        free(m->ctx);
+        free(devs);
+        free(m);
+        return 4;
+    }
+    memcpy(devs, devices, sizeof(int) * (size_t)n_devices);
+    m->n_devices = n_devices;
+    m->cfg = cfg;
+    m->networks = networks;
+    m->devices = devs;
+    m->n_tensors = n_tensors;
+    m->max_batch = max_batch_per_device;
+    m->precision = precision;
+    /* one "shard" per device: the replicas are built side by side (weight upload + repack each) */
+    const int rc = vit_shard_run(n_devices, n_devices, multi_create_one, m);
+    m->cfg = NULL;
+    m->networks = NULL;
+    if (rc != 0) {
+        vit_hip_destroy_multi(m);
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
+void vit_hip_destroy_multi(vit_hip_multi *m)
+{
+    if (!m)
+        return;
+    for (int d = 0; d < m->n_devices; ++d)
+        vit_hip_destroy(m->ctx[d]);
+    free((void *)m->devices);
+    free(m->ctx);
+    free(m);
+}
+
+int vit_hip_multi_devices(const vit_hip_multi *m) { return m ? m->n_devices : 0; }
+vit_hip_ctx *vit_hip_multi_ctx(const vit_hip_multi *m, int i) { return (m && i >= 0 && i < m->n_devices) ? m->ctx[i] : NULL; }
+
+static int multi_forward_one(void *arg, int shard, int lo, int hi)
+{
+    vit_hip_multi *m = (vit_hip_multi *)arg;
+    const size_t NC = (size_t)vit_hip_config(m->ctx[shard])->num_classes;
+    return vit_hip_forward(m->ctx[shard], m->images + lo, hi - lo, m->logits ? m->logits + (size_t)lo * NC : NULL,
+                           m->probs ? m->probs + lo : NULL);
+}
+
+/* Not re-entrant on one vit_hip_multi (like vit_hip_forward on one context). */
+int vit_hip_forward_multi(vit_hip_multi *m, const ImageData *images, int n, float *logits, float **probs)
+{
+    if (!m || !images || n <= 0)
+        return 1;
+    m->images = images;
+    m->logits = logits;
+    m->probs = probs;
+    return vit_shard_run(n, m->n_devices, multi_forward_one, m);
+}
+
+/* $VIT_HIP_DEVICES: "all", or a comma-separated list of device ids; returns the count written. */
+static int parse_devices(const char *env, int *out, int capacity)
+{
+    int n = 0;
+    if (!env || !*env)
+        return 0;
+    if (strcmp(env, "all") == 0) {
+        const int have = vh_device_count();
+        for (int d = 0; d < have && n < capacity; ++d)
+            out[n++] = d;
+        return n;
+    }
+    for (const char *p = env; *p && n < capacity;) {
+        char *end = NULL;
+        const long v = strtol(p, &end, 10);
+        if (end == p)
+            break;
+        out[n++] = (int)v;
+        p = (*end == ',') ? end + 1 : end;
+        if (*end != ',' && *end != '\0')
+            break;
+    }
+    return n;
+}
+
 /* The drop-in entry point (reference ViT_opencl.c:794).  Same observable
  * behaviour: fills probabilities[i][0..999]; prints a setup-time line and a
  * throughput line where the reference prints "setup time" / "picture #i". */
@@ -802,10 +1002,35 @@ void ViT_opencl(ImageData *image, Network *networks, float **probabilities)
     const char *env = getenv("VIT_HIP_DEVICE");
     if (env && *env)
         device = atoi(env);
-    int chunk = n < 512 ? n : 512;
+    int devices[64];
+    const int n_devices = parse_devices(getenv("VIT_HIP_DEVICES"), devices, 64);
+    const int per_device = n_devices > 1 ? (n + n_devices - 1) / n_devices : n;
+    int chunk = per_device < 512 ? per_device : 512;
     const char *envb = getenv("VIT_HIP_MAX_BATCH");
     if (envb && atoi(envb) > 0)
-        chunk = atoi(envb) < n ? atoi(envb) : n;
+        chunk = atoi(envb) < per_device ? atoi(envb) : per_device;
+    if (n_devices > 1) {
+        /* $VIT_HIP_DEVICES names several GPUs: contiguous shards of the images, one replica per device */
+        const char *envp = getenv("VIT_HIP_PRECISION");
+        const int precision = (envp && envp[0] == 'b') ? VIT_PRECISION_BF16_GEMM
+                            : (envp && strncmp(envp, "fp16x2", 6) == 0) ? VIT_PRECISION_F32_FP16X2 : VIT_PRECISION_F32;
+        vit_hip_multi *m = NULL;
+        int rcm = vit_hip_create_multi(&m, &cfg, networks, vit_config_num_tensors(&cfg), devices, n_devices, chunk, precision);
+        if (rcm != 0) {
+            printf("[%s:%d] vit_hip_create_multi failed (%d): %s\n", __FILE__, __LINE__, rcm, vh_last_error());
+            exit(EXIT_FAILURE);
+        }
+        const double t1m = wall_seconds();
+        printf("setup time: %.6f sec (%d devices)\n\n", t1m - t0, n_devices);
+        VH_CHECK(vit_hip_forward_multi(m, image, n, NULL, probabilities));
+        const double t2m = wall_seconds();
+        printf("pictures #0..#%d: %.6f sec (%.1f images/sec)\n\n", n - 1, t2m - t1m,
+               (double)n / (t2m - t1m > 0 ? t2m - t1m : 1e-9));
+        vit_hip_destroy_multi(m);
+        return;
+    }
+    if (n_devices == 1)
+        device = devices[0];
 
     vit_hip_ctx *ctx = NULL;
     int rc = vit_hip_create(&ctx, &cfg, networks, vit_config_num_tensors(&cfg), device, chunk);

@@ -408,20 +408,10 @@ int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, i
     /* rows per buffer: whole register groups of keys (8 for the fp32 MFMA, 16 for the split forms), whole 4-row DMA pieces */
     const int RB = NPL == 0 ? (T + 7) / 8 * 8 : (T + 15) / 16 * 16;
     const size_t lds = sizeof(float) * 3 * RB * HD + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)attention_f32_kernel<NKT, OUTK, NPL>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
-        attr_set = true;
-    }
+    VH_SET_LDS_ONCE((attention_f32_kernel<NKT, OUTK, NPL>), MAX_LDS);
     /* Persistent grid: one workgroup per CU (the three K/V buffers fill a CU's LDS),
      * each walking (image, head) items blockIdx.x, blockIdx.x + grid, ... */
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        VH_TRY(hipGetDevice(&dev));
-        VH_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int num_cus = vh_device_cus(vh_current_device());
     const int n_items = n_images * H;
     const int grid = n_items < num_cus ? n_items : num_cus;
     hipLaunchKernelGGL((attention_f32_kernel<NKT, OUTK, NPL>), dim3(grid), dim3(64 * NKT), lds, st, qkv, out,

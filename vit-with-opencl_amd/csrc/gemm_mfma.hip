@@ -854,12 +854,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
 template <class T, int AMODE, int EPI, int INK, int OUTK, bool SCHED = false, int NPL = 0>
 int launch_mf16(hipStream_t st, GemmParams p)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, NPL>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::lds(NPL)));
-        attr_set = true;
-    }
+    VH_SET_LDS_ONCE((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, NPL>), T::lds(NPL));
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = p.N / T::BN;
     hipLaunchKernelGGL((gemm_mf16_kernel<T, AMODE, EPI, INK, OUTK, SCHED, NPL>), dim3(p.mtiles * p.ntiles),
@@ -882,12 +877,7 @@ __global__ void cls_rows_kernel(const float *cls, const float *pos, float *token
 template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false, bool SPLIT3 = false>
 int launch_tile(hipStream_t st, GemmParams p)
 {
-    static bool attr_set = false; /* per instantiation; benign race (idempotent) */
-    if (!attr_set) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT, SPLIT3>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS));
-        attr_set = true;
-    }
+    VH_SET_LDS_ONCE((gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT, SPLIT3>), T::LDS);
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = (p.N + T::BN - 1) / T::BN;
     hipLaunchKernelGGL((gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT, SPLIT3>),
@@ -1221,14 +1211,12 @@ int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
     if (c != 3)
         return small_wide ? launch_mf16<Tile9, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p)
                           : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
-    static int num_cus = 0, tail = -1;
-    if (num_cus == 0) {
-        int dev = 0;
-        VH_TRY(hipGetDevice(&dev));
-        VH_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    static int tail = -1;
+    if (tail < 0) {
         const char *env = getenv("VIT_HIP_GEMM_TAIL");
         tail = (env && env[0] == '0') ? 0 : 1;
     }
+    const int num_cus = vh_device_cus(vh_current_device());
     const int ntiles = p.N / 256, mtiles = (p.M + 255) / 256;
     const long tiles = (long)mtiles * ntiles, full = tiles / num_cus, rem = tiles % num_cus;
     const int rows_big = (int)(full * num_cus / ntiles) * 256;

@@ -240,43 +240,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
     }
 }
 
-/* Per-device launch state (a process may hold contexts on several GPUs): dynamic-LDS attribute
- * set and CU count, keyed by the current device. */
-constexpr int MAX_DEVICES = 16;
-
-int current_device()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
-        return -1;
-    return dev;
-}
-
-int device_cus(int dev)
-{
-    static int cus[MAX_DEVICES];
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus[dev] = n;
-    }
-    return cus[dev];
-}
-
 template <int NW, int BN, int EPI, int OUTK>
 int launch_p3_tile(hipStream_t st, P3Params p)
 {
     constexpr int LDS = 2 * 3 * BN * 64;
-    static bool attr_set[MAX_DEVICES];
-    const int dev = current_device();
-    if (dev < 0)
-        return vh_fail(1, "gemm_p3: no current HIP device");
-    if (!attr_set[dev]) {
-        VH_TRY(hipFuncSetAttribute((const void *)gemm_p3_kernel<NW, BN, EPI, OUTK>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set[dev] = true;
-    }
+    VH_SET_LDS_ONCE((gemm_p3_kernel<NW, BN, EPI, OUTK>), LDS);
     p.mtiles = (p.row_end - p.row_begin + 32 * NW - 1) / (32 * NW);
     p.ntiles = p.N / BN;
     hipLaunchKernelGGL((gemm_p3_kernel<NW, BN, EPI, OUTK>), dim3(p.mtiles * p.ntiles), dim3(64 * NW), LDS, st, p);
@@ -294,10 +262,7 @@ int launch_p3(hipStream_t st, const P3Params &p, int small_only)
     const int rows = p.row_end - p.row_begin;
     if (p.N % 256 != 0 || rows < 4096 || small_only)
         return launch_p3_tile<4, 128, EPI, OUTK>(st, p);
-    const int dev = current_device();
-    if (dev < 0)
-        return vh_fail(1, "gemm_p3: no current HIP device");
-    const int num_cus = device_cus(dev);
+    const int num_cus = vh_device_cus(vh_current_device());
     const int ntiles = p.N / 256, mtiles = (rows + 255) / 256;
     const long tiles = (long)mtiles * ntiles, full = tiles / num_cus, rem = tiles % num_cus;
     const int rows_big = (int)(full * num_cus / ntiles) * 256;

@@ -74,6 +74,9 @@ int vh_init(int device)
 
 const char *vh_device_name(void) { return g_devname; }
 
+/* HIP's current device is per host thread: every context entry point re-selects its device. */
+int vh_set_device(int device) { VH_TRY(hipSetDevice(device)); return 0; }
+
 int vh_stream_create(vh_stream_t *out)
 {
     hipStream_t s;

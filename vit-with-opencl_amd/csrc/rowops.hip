@@ -277,14 +277,7 @@ extern "C" int vh_launch_layer_norm_p3(vh_stream_t s, const float *input, const 
     hipStream_t st = (hipStream_t)s;
 #define VH_LN3(NV)                                                                                        \
     do {                                                                                                  \
-        static bool attr_set[16];                                                                         \
-        int dev = 0;                                                                                      \
-        VH_TRY(hipGetDevice(&dev));                                                                       \
-        if (dev >= 0 && dev < 16 && !attr_set[dev]) {                                                     \
-            VH_TRY(hipFuncSetAttribute((const void *)layernorm_p3_kernel<NV>,                             \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));          \
-            attr_set[dev] = true;                                                                         \
-        }                                                                                                 \
+        VH_SET_LDS_ONCE((layernorm_p3_kernel<NV>), 160 * 1024);                                           \
         hipLaunchKernelGGL((layernorm_p3_kernel<NV>), grid, block, lds, st, input, weight, bias,          \
                            static_cast<char *>(out_planes), rows, embed_dim, in_row_stride, eps);         \
     } while (0)

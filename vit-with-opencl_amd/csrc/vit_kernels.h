@@ -32,6 +32,42 @@ int vh_hip_status(hipError_t e, const char *what);
 int vh_attention_tiled(void *stream, const float *qkv, void *output, int out_bf16, int n_images, int tokens,
                        int embed_dim, int num_heads);
 
+/* Launch state that is per DEVICE (a process may hold contexts on several GPUs, one host thread each):
+ * hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are cached per device id. */
+#define VH_MAX_DEVICES 16
+static inline int vh_current_device(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VH_MAX_DEVICES)
+        return -1;
+    return dev;
+}
+static inline int vh_device_cus(int dev)
+{
+    static int cus[VH_MAX_DEVICES];
+    if (dev < 0 || dev >= VH_MAX_DEVICES)
+        return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+/* once per (kernel instantiation, device): raise the dynamic-LDS limit of `func` to `bytes` */
+#define VH_SET_LDS_ONCE(func, bytes)                                                         \
+    do {                                                                                     \
+        static bool vh_attr_set_[VH_MAX_DEVICES];                                            \
+        const int vh_dev_ = vh_current_device();                                             \
+        if (vh_dev_ < 0)                                                                     \
+            return vh_fail(1, "no current HIP device (or device id >= %d)", VH_MAX_DEVICES); \
+        if (!vh_attr_set_[vh_dev_]) {                                                        \
+            VH_TRY(hipFuncSetAttribute((const void *)(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            vh_attr_set_[vh_dev_] = true;                                                    \
+        }                                                                                    \
+    } while (0)
+
 #define VH_TRY(expr)                                                           \
     do {                                                                       \
         hipError_t vh_try_e_ = (expr);                                         \

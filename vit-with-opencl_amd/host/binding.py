@@ -41,6 +41,8 @@ EXPORTS = [
     "vh_launch_layer_norm_fp8", "vh_launch_linear_fp8", "vit_hip_calibrate_fp8", "vit_hip_fp8_scales",
     "vh_launch_split3_rows", "vh_launch_merge3_rows", "vh_launch_layer_norm_p3", "vh_launch_attention_p3",
     "vh_launch_linear_p3",
+    "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
+    "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
     "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
     "vit_write_result_file", "vit_compare_rows",
@@ -74,6 +76,10 @@ class Network(C.Structure):
     """`Network` (include/Network.h; reference Network.h:19-23)."""
 
     _fields_ = [("data", f32p), ("size", C.c_size_t)]
+
+
+# int fn(void *arg, int shard, int lo, int hi) -- the callback type of vit_shard_run
+SHARD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 
 
 class VitHipError(RuntimeError):
@@ -178,6 +184,17 @@ def lib() -> C.CDLL:
     L.vit_hip_fp8_scales.argtypes = [voidp, f32p, i]
     L.vit_hip_destroy.argtypes = [voidp]
     L.vit_hip_destroy.restype = None
+    L.vh_set_device.argtypes = [i]
+    L.vit_hip_create_multi.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, C.POINTER(i), i, i, i]
+    L.vit_hip_forward_multi.argtypes = [voidp, C.POINTER(ImageData), i, f32p, C.POINTER(f32p)]
+    L.vit_hip_destroy_multi.argtypes = [voidp]
+    L.vit_hip_destroy_multi.restype = None
+    L.vit_hip_multi_devices.argtypes = [voidp]
+    L.vit_hip_multi_ctx.argtypes = [voidp, i]
+    L.vit_hip_multi_ctx.restype = voidp
+    L.vit_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+    L.vit_shard_range.restype = None
+    L.vit_shard_run.argtypes = [i, i, SHARD_FN, voidp]
     L.vit_hip_forward.argtypes = [voidp, C.POINTER(ImageData), i, f32p, C.POINTER(f32p)]
     L.vit_hip_forward_device.argtypes = [voidp, voidp, i, voidp, voidp, voidp]
     L.vit_hip_stream.argtypes = [voidp]
@@ -378,6 +395,39 @@ class ViTHip:
         if self.ctx:
             self.L.vit_hip_destroy(self.ctx)
             self.ctx = voidp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ViTHipMulti:
+    """One replica per device behind one call (vit_hip_create_multi / forward_multi / destroy_multi)."""
+
+    def __init__(self, cfg: VitConfig, weights: list[np.ndarray], devices: list[int], max_batch_per_device: int = 64,
+                 precision: str = "f32"):
+        self.cfg, self.L = cfg, lib()
+        self.handle = voidp()
+        devs = (C.c_int * len(devices))(*devices)
+        check(self.L.vit_hip_create_multi(C.byref(self.handle), C.byref(cfg), networks(weights), len(weights), devs,
+                                          len(devices), max_batch_per_device,
+                                          {"f32": 0, "bf16": 1, "fp8": 2, "f32_fp16x2": 3}[precision]), "vit_hip_create_multi")
+
+    def forward(self, images: np.ndarray):
+        images = np.ascontiguousarray(images, dtype=np.float32)
+        n, nc = images.shape[0], self.cfg.num_classes
+        logits = np.empty((n, nc), dtype=np.float32)
+        probs = np.empty((n, nc), dtype=np.float32)
+        rows = (f32p * n)(*[fptr(probs[i]) for i in range(n)])
+        check(self.L.vit_hip_forward_multi(self.handle, image_array(images), n, fptr(logits), rows), "vit_hip_forward_multi")
+        return logits, probs
+
+    def close(self):
+        if self.handle:
+            self.L.vit_hip_destroy_multi(self.handle)
+            self.handle = voidp()
 
     def __del__(self):
         try:
