@@ -435,10 +435,56 @@ def test_torch_interop_shares_one_hip_runtime(pkg, device, weights, golden_full)
     imgs = torch.from_numpy(pkg.synth_images(cfg, 0, 2)).cuda()
     logits = torch.empty(2, 1000, device="cuda")
     torch.cuda.synchronize()
-    m.forward_device(imgs.data_ptr(), 2, logits.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert np.abs(logits.cpu().numpy() - golden_full["logits"][:2]).max() <= LOGIT_TOL
+    # a torch SIDE stream: its handle is non-zero (handle 0 means "the context's own stream" to the
+    # library, which torch does not order against), and torch work queued on it follows the forward
+    side = torch.cuda.Stream()
+    assert side.cuda_stream != 0
+    m.forward_device(imgs.data_ptr(), 2, logits.data_ptr(), None, side.cuda_stream)
+    with torch.cuda.stream(side):
+        host = logits.to("cpu", non_blocking=False).numpy()      # ordered after the kernels by the stream alone
+    assert np.abs(host - golden_full["logits"][:2]).max() <= LOGIT_TOL
     m.close()
+
+
+def test_rccl_gather_is_ordered_after_the_forward(tmp_path):
+    """bench.py's N > 1 step on one GPU (VIT_DIST_FORCE=1: an RCCL group of world size 1): the forward
+    is launched on a torch side stream and the gather of the logits is enqueued on the same stream, with
+    NO host synchronisation in between and DIFFERENT images every step -- the gathered rows must equal a
+    synchronised forward of the same images (a gather that overtook the kernels would return the previous
+    step's logits)."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, os, numpy as np; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "import __graft_entry__ as g\n"
+        "pkg = g.load_package()\n"
+        "from vit_with_opencl_amd.host.dist import Comm\n"
+        "comm = Comm()\n"
+        "assert comm.active and comm.backend == 'nccl'\n"
+        "cfg = pkg.preset('vit_b_16'); w = pkg.synth_weights(cfg, 0)\n"
+        "m = pkg.ViTHip(cfg, w, device=0, max_batch=4)\n"
+        "side = torch.cuda.Stream(); assert side.cuda_stream != 0\n"
+        "t_logits = torch.empty(4, 1000, device='cuda')\n"
+        "for step in range(3):\n"
+        "    imgs = torch.from_numpy(pkg.synth_images(cfg, 4 * step, 4)).cuda()\n"
+        "    torch.cuda.synchronize()\n"
+        "    m.forward_device(imgs.data_ptr(), 4, t_logits.data_ptr(), None, side.cuda_stream)\n"
+        "    with torch.cuda.stream(side):\n"
+        "        got = comm.gather_rows(t_logits)[0].clone()\n"
+        "    side.synchronize()\n"
+        "    ref = torch.empty(4, 1000, device='cuda')\n"
+        "    m.forward_device(imgs.data_ptr(), 4, ref.data_ptr(), None, side.cuda_stream)\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert torch.equal(got, ref), step\n"
+        "m.close(); comm.close(); print('ok')\n"
+    ) % str(root)
+    env = dict(os.environ, VIT_DIST_FORCE="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
 
 
 def test_vit_l16_one_image_vs_oracle(pkg, device):
