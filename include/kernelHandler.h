@@ -142,6 +142,18 @@ int vh_launch_linear_w3(vh_stream_t s, float *output, const void *weight_planes,
  * around ll.cl:7 / multihead.cl:3 / layer_norm.cl:3); rows < 2^26, cols % 32 == 0, 16-byte aligned. */
 int vh_launch_split3_rows(vh_stream_t s, const float *input, void *planes, int rows, int cols);
 int vh_launch_merge3_rows(vh_stream_t s, const void *planes, float *output, int rows, int cols); /* exact inverse */
+/* The same format with `parts` parts per value: 3 as above, or 1 = values rounded to bfloat16 (the operands of
+ * the bf16-operand mode, BASELINE config 3), planes[cols/32][1][rows][32]: the same GEMM kernel takes both. */
+int vh_launch_split_rows(vh_stream_t s, const float *input, void *planes, int rows, int cols, int parts);
+int vh_launch_merge_rows(vh_stream_t s, const void *planes, float *output, int rows, int cols, int parts);
+int vh_launch_layer_norm_planes(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                                void *out_planes, int parts, int rows, int embed_dim, long in_row_stride, double eps);
+int vh_launch_attention_planes_bf16(vh_stream_t s, const float *qkv, void *out_planes, int n_images, int tokens,
+                                    int embed_dim, int num_heads);   /* one-part planes, arithmetic of vh_launch_attention_bf16 */
+/* colA % 64 == 0 (parts 3) or % 128 == 0 (parts 1); fp32 accumulation, bias, GELU, residual as vh_launch_linear */
+int vh_launch_linear_planes(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
+                            const void *input_planes, int parts, const float *bias, int rowA, int colA, int colB,
+                            int doGelu, const float *residual);
 /* vh_launch_layer_norm writing planes [embed_dim/32][3][rows][32] */
 int vh_launch_layer_norm_p3(vh_stream_t s, const float *input, const float *weight, const float *bias,
                             void *out_planes, int rows, int embed_dim, long in_row_stride, double eps);

@@ -226,3 +226,76 @@ def test_model_p3_full_batch_tile_paths(pkg, device, weights):
     ls, _ = small.forward(imgs[pick])
     small.close()
     assert np.array_equal(lb[pick], ls)
+
+
+# ---- the same kernel with ONE part per value: the bf16-operand mode (BASELINE config 3) -----------
+
+
+def _planes1_to_f32(buf, rows, cols):
+    raw = buf.to_numpy().view(np.uint16)[:rows * cols].reshape(cols // 32, 1, rows, 32)
+    return (raw.astype(np.uint32) << 16).view(np.float32).transpose(1, 2, 0, 3).reshape(rows, cols)
+
+
+@pytest.mark.parametrize("M,K,N,gelu,resid,planes_out", [
+    (197, 768, 2304, 0, False, False),     # QKV: planes in, fp32 out
+    (197, 768, 768, 0, True, False),       # out-projection + residual
+    (300, 768, 3072, 1, False, True),      # fc1 + GELU, one-part planes out
+    (300, 3072, 768, 0, True, False),      # fc2 + residual
+    (5, 128, 128, 0, False, True),         # smallest legal shape
+    (19700, 768, 2304, 0, False, False),   # 100 images: 256x256 tiles + a tail launch of 128x128 tiles
+    (60000, 3072, 768, 0, True, False),    # long K, big tiles + tail
+])
+def test_linear_planes_one_part_vs_oracle_on_bf16_rounded_operands(pkg, device, oracle, M, K, N, gelu, resid, planes_out):
+    """vh_launch_linear_planes(parts = 1): operands rounded to bf16 by vh_launch_split_rows(parts = 1),
+    fp32 accumulation.  The oracle's fp32 loop (ViT_seq.c:295-309) on the SAME rounded operands differs
+    only by summation order, so the fp32 operator tolerance applies (rows sampled around tile and launch
+    boundaries for the large shapes)."""
+    x = oracle.synth_fill(M * K, 700 + M, 1.0, 0.1).reshape(M, K)
+    w = oracle.synth_fill(N * K, 701 + N, 0.04, 0.0)
+    b = oracle.synth_fill(N, 702, 0.1, 0.0)
+    r = oracle.synth_fill(M * N, 703, 1.0, 0.0).reshape(M, N)
+    d_x, d_w, d_b = _dev(pkg, x), _dev(pkg, w), _dev(pkg, b)
+    d_w1, d_x1 = pkg.DeviceBuffer((N * K + 1) // 2), pkg.DeviceBuffer((M * K + 1) // 2)
+    _launch(pkg, "vh_launch_split_rows", None, d_w.ptr, d_w1.ptr, N, K, 1)
+    _launch(pkg, "vh_launch_split_rows", None, d_x.ptr, d_x1.ptr, M, K, 1)
+    xr, wr = _planes1_to_f32(d_x1, M, K), _planes1_to_f32(d_w1, N, K)
+    assert np.array_equal(xr, _bf16_rne(x)) and np.array_equal(wr.ravel(), _bf16_rne(w))     # format + rounding
+    if planes_out:
+        d_o1 = pkg.DeviceBuffer((M * N + 1) // 2)
+        _launch(pkg, "vh_launch_linear_planes", None, d_o1.ptr, 1, d_w1.ptr, d_x1.ptr, 1, d_b.ptr, M, K, N, gelu, None)
+        got = _planes1_to_f32(d_o1, M, N)
+    else:
+        d_o = _dev(pkg, r) if resid else pkg.DeviceBuffer(M * N)
+        _launch(pkg, "vh_launch_linear_planes", None, d_o.ptr, 0, d_w1.ptr, d_x1.ptr, 1, d_b.ptr, M, K, N, gelu,
+                d_o.ptr if resid else None)
+        got = d_o.to_numpy((M, N))
+    rb = _rows_big(M, K, N, resid)
+    rows = np.arange(M) if M <= 300 else _sample_rows(M, extra=(256, 4096, rb, rb + 128) if rb else (256, 4096))
+    want = oracle.linear(xr[rows], wr.ravel(), b, N)
+    if gelu:
+        want = oracle.gelu(want.ravel()).reshape(len(rows), N)
+    if resid:
+        want = r[rows] + want
+    tol = OP_TOL + (2.0 ** -8 * np.abs(want).max() if planes_out else 0.0)          # one bf16 rounding of the output
+    assert np.abs(got[rows] - want).max() <= tol
+
+
+def test_layer_norm_and_attention_one_part_planes_equal_their_bf16_twins(pkg, device, oracle, weights):
+    """vh_launch_layer_norm_planes(parts = 1) and vh_launch_attention_planes_bf16 write the values of
+    vh_launch_layer_norm_bf16 / vh_launch_attention_bf16 (row-major bf16), in plane order."""
+    rows, E, H = 1000, 768, 12
+    x = oracle.synth_fill(rows * E, 31, 3.0, 0.5).reshape(rows, E)
+    d_x, d_g, d_b = _dev(pkg, x), _dev(pkg, weights[4]), _dev(pkg, weights[5])
+    d_y16, d_p1 = pkg.DeviceBuffer(rows * E // 2), pkg.DeviceBuffer(rows * E // 2)
+    _launch(pkg, "vh_launch_layer_norm_bf16", None, d_x.ptr, d_g.ptr, d_b.ptr, d_y16.ptr, rows, E, E, E, 1e-6)
+    _launch(pkg, "vh_launch_layer_norm_planes", None, d_x.ptr, d_g.ptr, d_b.ptr, d_p1.ptr, 1, rows, E, E, 1e-6)
+    twin = (d_y16.to_numpy().view(np.uint16)[:rows * E].astype(np.uint32) << 16).view(np.float32).reshape(rows, E)
+    assert np.array_equal(_planes1_to_f32(d_p1, rows, E), twin)
+    n_images, tokens = 3, 197
+    rows = n_images * tokens
+    qkv = oracle.synth_fill(rows * 3 * E, 78, 1.0, 0.0)
+    d_q, d_o16, d_o1 = _dev(pkg, qkv), pkg.DeviceBuffer(rows * E // 2 + 1), pkg.DeviceBuffer(rows * E // 2 + 1)
+    _launch(pkg, "vh_launch_attention_bf16", None, d_q.ptr, d_o16.ptr, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_attention_planes_bf16", None, d_q.ptr, d_o1.ptr, n_images, tokens, E, H)
+    twin = (d_o16.to_numpy().view(np.uint16)[:rows * E].astype(np.uint32) << 16).view(np.float32).reshape(rows, E)
+    assert np.array_equal(_planes1_to_f32(d_o1, rows, E), twin)

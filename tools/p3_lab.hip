@@ -18,22 +18,23 @@ __global__ void fill_random(float *x, size_t n, unsigned seed, float scale)
 }
 #define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int NW, int BN, int EPI, int OUTK, int LAB>
+template <int NW, int BN, int EPI, int OUTK, int LAB, int NPL = 3>
 void launch_variant(hipStream_t st, P3Params p)
 {
-    constexpr int LDS = 2 * 3 * BN * 64;
+    constexpr int LDS = 2 * (NPL == 3 ? 1 : 2) * NPL * BN * 64;
     static bool set = false;
-    if (!set) { CK(hipFuncSetAttribute((const void *)gemm_p3_kernel<NW, BN, EPI, OUTK, LAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
+    if (!set) { CK(hipFuncSetAttribute((const void *)gemm_p3_kernel<NW, BN, EPI, OUTK, NPL, LAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
     p.mtiles = (p.row_end - p.row_begin + 32 * NW - 1) / (32 * NW);
     p.ntiles = p.N / BN;
-    hipLaunchKernelGGL((gemm_p3_kernel<NW, BN, EPI, OUTK, LAB>), dim3(p.mtiles * p.ntiles), dim3(64 * NW), LDS, st, p);
+    hipLaunchKernelGGL((gemm_p3_kernel<NW, BN, EPI, OUTK, NPL, LAB>), dim3(p.mtiles * p.ntiles), dim3(64 * NW), LDS, st, p);
 }
 }
 
 int main(int argc, char **argv)
 {
-    int M = 98304, N = 3072, K = 768;
+    int M = 98304, N = 3072, K = 768, parts = 3;
     if (argc >= 4) { M = atoi(argv[1]); N = atoi(argv[2]); K = atoi(argv[3]); }
+    if (argc >= 5) parts = atoi(argv[4]);
     CK(hipSetDevice(0));
     hipStream_t st; CK(hipStreamCreate(&st));
     float *x, *w, *bias; char *x3, *w3, *c3;
@@ -42,24 +43,52 @@ int main(int argc, char **argv)
     fill_random<<<(unsigned)(((size_t)M * K + 255) / 256), 256, 0, st>>>(x, (size_t)M * K, 1u, 1.0f);
     fill_random<<<(unsigned)(((size_t)N * K + 255) / 256), 256, 0, st>>>(w, (size_t)N * K, 2u, 0.04f);
     fill_random<<<(N + 255) / 256, 256, 0, st>>>(bias, (size_t)N, 3u, 0.1f);
-    if (vh_launch_split3_rows(st, x, x3, M, K) || vh_launch_split3_rows(st, w, w3, N, K)) { printf("split failed\n"); return 1; }
+    if (vh_launch_split_rows(st, x, x3, M, K, parts) || vh_launch_split_rows(st, w, w3, N, K, parts)) { printf("split failed\n"); return 1; }
     CK(hipStreamSynchronize(st));
     P3Params p = {};
     p.A = x3; p.W = w3; p.bias = bias; p.C = c3; p.row_begin = 0; p.row_end = M; p.a_rows = M; p.N = N; p.K = K;
 
     struct V { const char *name; void (*fn)(hipStream_t, P3Params); };
     std::vector<V> vs = {
-        {"product (fc1: GELU, planes out)", launch_variant<8, 256, EPI_GELU, OUT_P3, 0>},
-        {"no W fragment reads            ", launch_variant<8, 256, EPI_GELU, OUT_P3, 1>},
-        {"no W DMA                       ", launch_variant<8, 256, EPI_GELU, OUT_P3, 2>},
-        {"no A loads                     ", launch_variant<8, 256, EPI_GELU, OUT_P3, 4>},
-        {"no reads, no DMA, no A loads   ", launch_variant<8, 256, EPI_GELU, OUT_P3, 7>},
-        {"... and no barrier             ", launch_variant<8, 256, EPI_GELU, OUT_P3, 15>},
+        {"product (fc1: GELU, planes out)", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0>},
+        {"no W fragment reads            ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 1>},
+        {"no W DMA                       ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 2>},
+        {"no A loads                     ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 4>},
+        {"no reads, no DMA, no A loads   ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 7>},
+        {"... and no barrier             ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 15>},
         {"product, no GELU, fp32 out     ", launch_variant<8, 256, EPI_NONE, OUT_F32, 0>},
-        {"A rows of tile 0 everywhere    ", launch_variant<8, 256, EPI_GELU, OUT_P3, 16>},
-        {"W rows of tile 0 everywhere    ", launch_variant<8, 256, EPI_GELU, OUT_P3, 32>},
-        {"A and W of tile 0 everywhere   ", launch_variant<8, 256, EPI_GELU, OUT_P3, 48>},
+        {"A rows of tile 0 everywhere    ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 16>},
+        {"W rows of tile 0 everywhere    ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 32>},
+        {"A and W of tile 0 everywhere   ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 48>},
+        {"no epilogue stores             ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64>},
+        {"no stores, no reads/DMA/A loads", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64 + 7>},
     };
+    if (parts == 1)
+        vs = {
+            {"bf16 product (fc1: GELU, planes) ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"no W fragment reads              ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 1, 1>},
+            {"no W DMA                         ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 2, 1>},
+            {"no A loads                       ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 4, 1>},
+            {"no reads, no DMA, no A loads     ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 7, 1>},
+            {"... and no barrier               ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 15, 1>},
+            {"product, no GELU, fp32 out       ", launch_variant<8, 256, EPI_NONE, OUT_F32, 0, 1>},
+            {"A and W of tile 0 everywhere     ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 48, 1>},
+            {"small tile 128x128               ", launch_variant<4, 128, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"128x256 tile, 2 workgroups/CU    ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"128x256, no stores               ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 64, 1>},
+            {"128x256, no A loads              ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 4, 1>},
+            {"128x256, no DMA                  ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 2, 1>},
+            {"128x256, no W reads              ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 1, 1>},
+
+
+
+
+
+
+            {"no epilogue stores               ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64, 1>},
+            {"no stores, no reads/DMA/A loads  ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64 + 7, 1>},
+            {"no stores/reads/DMA/A/barrier    ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 64 + 15, 1>},
+        };
     const int ROUNDS = 4, REPS = 10;
     std::vector<double> best(vs.size(), 1e30), sum(vs.size(), 0.0);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -78,7 +107,7 @@ int main(int argc, char **argv)
     const double flop = 2.0 * M * N * K;
     printf("M=%d N=%d K=%d, %d rounds x %d launches, random operands\n", M, N, K, ROUNDS, REPS);
     for (size_t i = 0; i < vs.size(); ++i)
-        printf("%s  mean %.3f ms  min %.3f ms  %.1f TFLOP/s fp32-equivalent (%.0f bf16 MFMA TFLOP/s)\n", vs[i].name,
-               sum[i] / ROUNDS, best[i], flop / (sum[i] / ROUNDS * 1e-3) / 1e12, 6 * flop / (sum[i] / ROUNDS * 1e-3) / 1e12);
+        printf("%s  mean %.3f ms  min %.3f ms  %.1f TFLOP/s of products (%.0f bf16 MFMA TFLOP/s)\n", vs[i].name,
+               sum[i] / ROUNDS, best[i], flop / (sum[i] / ROUNDS * 1e-3) / 1e12, (parts == 3 ? 6 : 1) * flop / (sum[i] / ROUNDS * 1e-3) / 1e12);
     return 0;
 }

@@ -349,8 +349,9 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
             load_q(next);
         }
 
-        if (OUTK == 3) {
-            /* Consumed only by the pre-split output projection: planes [E/32][3][rows][32], K step 2h + dt.
+        if (OUTK == 3 || OUTK == 4) {
+            /* Consumed only by the planes output projection: planes [E/32][NP][rows][32] (NP = 3: the exact split;
+             * OUTK == 4: NP = 1, values rounded to bf16 for the bf16-operand mode), K step 2h + dt.
              * A lane holds d = 8g + 4lh .. +3 (8 bytes per part); one half-wave exchange per dword
              * (v_permlane32_swap) gives the lower half the 16 bytes of group g and the upper half those of
              * group g+1.  Lanes l and l + 32 share a query, so the guard keeps pairs together. */
@@ -358,20 +359,25 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const size_t prow = (size_t)(n_items / H) * T;
+                constexpr int NP = OUTK == 3 ? 3 : 1;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     u32x2 pg[4][3];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         bf16x4 part[3];
-                        split4(f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]}, part[0], part[1], part[2]);
+                        const f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                        if (NP == 3)
+                            split4(v, part[0], part[1], part[2]);
+                        else
+                            part[0] = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
+                        for (int pl = 0; pl < NP; ++pl)
                             pg[g][pl] = __builtin_bit_cast(u32x2, part[pl]);
                     }
-                    char *d3 = static_cast<char *>(out) + ((size_t)(2 * h + dt) * 3 * prow + (size_t)b * T + q) * 64 + 16 * lh;
+                    char *d3 = static_cast<char *>(out) + ((size_t)(2 * h + dt) * NP * prow + (size_t)b * T + q) * 64 + 16 * lh;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                         for (int g = 0; g < 4; g += 2) {
                             const auto r0 = __builtin_amdgcn_permlane32_swap(pg[g][pl][0], pg[g + 1][pl][0], false, false);
@@ -427,6 +433,9 @@ int launch(hipStream_t st, const float *qkv, void *out, int out_bf16, int arith,
 {
     if (out_bf16 == 3)   /* planes for the pre-split output projection (exact split only) */
         return launch_k<NKT, 3, 3>(st, qkv, out, n_images, T, E, H);
+    if (out_bf16 == 4)   /* one-part (bf16) planes; products on fp16-rounded operands like the other reduced modes */
+        return arith == 1 ? launch_k<NKT, 4, 1>(st, qkv, out, n_images, T, E, H)
+                          : launch_k<NKT, 4, 3>(st, qkv, out, n_images, T, E, H);
     if (arith == 2 && !out_bf16)
         return launch_k<NKT, false, 2>(st, qkv, out, n_images, T, E, H);
     if (arith == 1)
@@ -456,7 +465,7 @@ static int launch_attention(vh_stream_t s, const float *qkv, void *output, int o
         const char *env = getenv("VIT_HIP_ATTN");
         force_tiled = (env && env[0] == 't') ? 1 : 0;
     }
-    if (embed_dim != num_heads * HD || tokens > MAX_ROWS || (force_tiled && out_bf16 != 3))
+    if (embed_dim != num_heads * HD || tokens > MAX_ROWS || (force_tiled && out_bf16 < 3))
         return vh_attention_tiled(s, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
     static int native = -1;
     if (native < 0) {
@@ -503,6 +512,21 @@ extern "C" int vh_launch_attention_p3(vh_stream_t s, const float *qkv, void *out
     if (embed_dim != num_heads * HD || tokens > MAX_ROWS)
         return vh_fail(1, "vh_launch_attention_p3: needs head_dim 64 and tokens <= %d", MAX_ROWS);
     return launch_attention(s, qkv, out_planes, 3, 3, n_images, tokens, embed_dim, num_heads);
+}
+
+/* The bf16-operand mode's attention writing one-part planes [E/32][1][n_images*tokens][32] (bf16) for
+ * vh_launch_linear_planes(parts = 1); same arithmetic as vh_launch_attention_bf16. */
+extern "C" int vh_launch_attention_planes_bf16(vh_stream_t s, const float *qkv, void *out_planes, int n_images,
+                                               int tokens, int embed_dim, int num_heads)
+{
+    if (embed_dim != num_heads * HD || tokens > MAX_ROWS)
+        return vh_fail(1, "vh_launch_attention_planes_bf16: needs head_dim 64 and tokens <= %d", MAX_ROWS);
+    static int lowp = -1;
+    if (lowp < 0) {
+        const char *env = getenv("VIT_HIP_ATTN_LOWP");
+        lowp = (env && env[0] == '0') ? 0 : 1;
+    }
+    return launch_attention(s, qkv, out_planes, 4, lowp ? 1 : 3, n_images, tokens, embed_dim, num_heads);
 }
 
 /* The emulation mode's attention: Q.K^T and P.V on two fp16 parts / three products (kernelHandler.h,

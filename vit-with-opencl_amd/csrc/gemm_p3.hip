@@ -55,14 +55,14 @@ typedef const __attribute__((address_space(1))) char *gchar_t;     /* global-mem
 typedef const __attribute__((address_space(1))) f32x4 *gvec_t;
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2 };
-enum { OUT_F32 = 0, OUT_P3 = 1 };
+enum { OUT_F32 = 0, OUT_PLANES = 1 };
 
 struct P3Params {
-    const char *A;            /* activation planes [K/32][3][a_rows][32] bf16 */
-    const char *W;            /* weight planes     [K/32][3][N][32] bf16 */
+    const char *A;            /* activation planes [K/32][NPL][a_rows][32] bf16 */
+    const char *W;            /* weight planes     [K/32][NPL][N][32] bf16 */
     const float *bias;        /* [N] */
     const float *R;           /* residual [a_rows][N] fp32 (EPI_RESID) */
-    void *C;                  /* fp32 [a_rows][N], or planes [N/32][3][a_rows][32] */
+    void *C;                  /* fp32 [a_rows][N], or planes [N/32][NPL][a_rows][32] */
     int row_begin, row_end;   /* rows of the activation matrix this launch covers */
     int N, K;
     int a_rows;               /* rows of the whole activation matrix = the planes' row count */
@@ -72,17 +72,28 @@ struct P3Params {
 /* 16-byte chunk swizzle of a 64-byte LDS row r: f((r >> 2) & 3), f = {0, 2, 3, 1} */
 __device__ __forceinline__ int swz64(int r4) { return (0x78 >> (2 * (r4 & 3))) & 3; }
 
-/* LAB (tools/p3_lab.hip only; 0 in the library): bit 0 skips the W fragment reads after the first step, bit 1
+/* NPL = parts per value: 3 = the exact fp32 split (six products per block, the default fp32 path);
+ * 1 = operands rounded to bf16 by their producers (one product per block: BASELINE config 3's
+ * bf16-operand mode).  With one part a W fragment feeds 2 MFMAs instead of 12, so a stage holds two
+ * 32-deep K groups (one barrier per 64 k) and four fragments are in flight in registers.
+ * LAB (tools/p3_lab.hip only; 0 in the library): bit 0 skips the W fragment reads after the first step, bit 1
  * the W DMA after the prologue, bit 2 the A loads after the prologue, bit 3 the barrier, bit 4 makes every
- * workgroup load the A rows of tile 0, bit 5 the W rows of tile 0 (operands served by L2 alone) -- throw-away
+ * workgroup load the A rows of tile 0, bit 5 the W rows of tile 0 (operands served by L2 alone), bit 6 drops
+ * the epilogue's stores -- throw-away
  * ablations that price each data movement; their results are wrong by construction. */
-template <int NW, int BN, int EPI, int OUTK, int LAB = 0>
+template <int NW, int BN, int EPI, int OUTK, int NPL = 3, int LAB = 0>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
 {
     constexpr int BM = 32 * NW, JT = BN / 16;
-    constexpr int STAGE = 3 * BN * 64;            /* bytes per LDS stage: [part][BN][64] */
-    constexpr int PW = 3 * BN / 16 / NW;          /* 1-KiB DMA pieces per wave and stage */
-    static_assert(JT % 2 == 0 && (3 * BN / 16) % NW == 0, "tile shape");
+    constexpr int KG = NPL == 3 ? 1 : 2;       /* 32-deep K groups per LDS stage */
+    constexpr int RING = NPL == 3 ? 2 : 4;          /* W fragments in flight in registers */
+    constexpr int F = KG * JT;                      /* W fragments per step */
+    constexpr int NT = NPL == 3 ? 6 : 1;            /* products per block */
+    constexpr int GROUP = NPL * BN * 64;            /* bytes of one K group in a stage: [part][BN][64] */
+    constexpr int STAGE = KG * GROUP;
+    constexpr int PW = KG * NPL * BN / 16 / NW;     /* 1-KiB DMA pieces per wave and stage */
+    static_assert(NPL == 1 || NPL == 3, "parts per value");
+    static_assert(JT % 2 == 0 && (KG * NPL * BN / 16) % NW == 0 && F % RING == 0, "tile shape");
     typedef bf16x8 frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,73 +131,85 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
         acc[1][j] = bv;
     }
 
-    frag_t a0[2][3], a1[2][3], w[2][3];
+    frag_t a0[KG][2][NPL], a1[KG][2][NPL], w[RING][NPL];
 
     /* Uniform (SGPR) base + 32-bit per-lane offset, the base made opaque per step: otherwise the
      * compiler keeps one 64-bit per-lane induction pointer per load (24 VGPRs, spilled). */
-    auto load_a = [&](frag_t (&a)[2][3], int kt) {
+    auto load_a = [&](frag_t (&a)[KG][2][NPL], int kt) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            gchar_t base = (gchar_t)p.A + (size_t)(kt * 3 + pl) * a_plane;
-            asm volatile("" : "+s"(base));
+        for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                a[i][pl] = __builtin_bit_cast(frag_t, *reinterpret_cast<gvec_t>(base + aoff[i]));
-        }
+            for (int pl = 0; pl < NPL; ++pl) {
+                gchar_t base = (gchar_t)p.A + (size_t)((kt * KG + kg) * NPL + pl) * a_plane;
+                asm volatile("" : "+s"(base));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[kg][i][pl] = __builtin_bit_cast(frag_t, *reinterpret_cast<gvec_t>(base + aoff[i]));
+            }
     };
     auto dma_w = [&](int stage, int kt) {
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int pc = wave * PW + i, plane = pc / (BN / 16), rb = pc - plane * (BN / 16);
-            gchar_t src = wtile + ((size_t)(kt * 3 + plane) * w_plane + (size_t)rb * 1024);
+            const int pc = wave * PW + i, gp = pc / (BN / 16), rb = pc - gp * (BN / 16);   /* gp = kg * NPL + part */
+            gchar_t src = wtile + ((size_t)(kt * KG * NPL + gp) * w_plane + (size_t)rb * 1024);
             asm volatile("" : "+s"(src));
             __builtin_amdgcn_global_load_lds((gptr_t)(src + wlane), (lptr_t)(smem + stage * STAGE + pc * 1024), 16, 0, 0);
         }
     };
-    auto read_w = [&](frag_t (&wf)[3], const char *stage, int j) {
+    auto read_w = [&](frag_t (&wf)[NPL], const char *stage, int f) {
+        const int kg = f / JT, j = f % JT;
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {   /* in the order the products need them: part 0, 2, 1 */
-            const int pl = (3 - o) % 3;
+        for (int o = 0; o < NPL; ++o) {   /* in the order the products need them: part 0, 2, 1 */
+            const int pl = (NPL - o) % NPL;
             wf[pl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const f32x4 *>(
-                                                    stage + ((j & 1) ? woff_o : woff_e) + (j >> 1) * 2048 + pl * (BN * 64)));
+                                                    stage + kg * GROUP + ((j & 1) ? woff_o : woff_e) + (j >> 1) * 2048 + pl * (BN * 64)));
         }
     };
-    auto mfma_frag = [&](const frag_t (&a)[2][3], const frag_t (&wf)[3], int j) {
+    auto mfma_frag = [&](const frag_t (&a)[KG][2][NPL], const frag_t (&wf)[NPL], int f) {
+        const int kg = f / JT, j = f % JT;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) /* per accumulator: smallest terms first */
+        for (int t = 0; t < NT; ++t) /* per accumulator: smallest terms first */
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                acc[i][j] = mfma_part(wf[term_w<3>(t)], a[i][term_a<3>(t)], acc[i][j]);
+                acc[i][j] = mfma_part(wf[term_w<NPL>(t)], a[kg][i][term_a<NPL>(t)], acc[i][j]);
+    };
+    /* fragment f+RING-1 is fetched under fragment f's MFMAs (left alone, the compiler issues each read
+     * right before its use and the matrix pipe waits out the LDS latency) */
+    auto interleave = [&]() {
+#pragma unroll
+        for (int r = 0; r < NPL; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        if (2 * NT > 2 * NPL)
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT - 2 * NPL, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
-    const int nk = p.K / 32;
-    auto step = [&](const frag_t (&au)[2][3], frag_t (&al)[2][3], int kt) {
+    const int nk = p.K / (32 * KG);
+    auto step = [&](const frag_t (&au)[KG][2][NPL], frag_t (&al)[KG][2][NPL], int kt) {
         const char *cur = smem + (kt & 1) * STAGE, *nxt = smem + ((kt + 1) & 1) * STAGE;
         const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
         if (more1 && !(LAB & 4))
             load_a(al, kt + 1);
 #pragma unroll
-        for (int j = 0; j < JT - 1; ++j) {
+        for (int f = 0; f <= F - RING; ++f) {
             if (!(LAB & 1) || kt == 0)
-                read_w(w[(j + 1) & 1], cur, j + 1);
-            mfma_frag(au, w[j & 1], j);
-            /* fragment j+1 is fetched under fragment j's MFMAs (left alone, the compiler issues each read
-             * right before its use and the matrix pipe waits out the LDS latency) */
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                read_w(w[(f + RING - 1) % RING], cur, f + RING - 1);
+            mfma_frag(au, w[f % RING], f);
+            interleave();
         }
         if (!(LAB & 8))
-            __syncthreads();   /* stage kt read by every wave (its last fragment is in registers); stage kt+1 has landed */
+            __syncthreads();   /* stage kt read by every wave (its last fragments are in registers); stage kt+1 has landed */
         if (more2 && !(LAB & 2))
             dma_w(kt & 1, kt + 2);
-        if (more1 && (!(LAB & 1) || kt == 0))
-            read_w(w[0], nxt, 0);
-        mfma_frag(au, w[(JT - 1) & 1], JT - 1);
+#pragma unroll
+        for (int f = F - RING + 1; f < F; ++f) {
+            if (more1 && (!(LAB & 1) || kt == 0))
+                read_w(w[(f + RING - 1) % RING], nxt, f + RING - 1 - F);
+            mfma_frag(au, w[f % RING], f);
+            interleave();
+        }
     };
 
     dma_w(0, 0);
@@ -194,7 +217,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
     __syncthreads();
     if (nk > 1)
         dma_w(1, 1);
-    read_w(w[0], smem, 0);
+#pragma unroll
+    for (int f = 0; f < RING - 1; ++f)
+        read_w(w[f], smem, f);
     for (int kt = 0; kt < nk; kt += 2) {   /* nk is even (launcher) */
         step(a0, a1, kt);
         if (LAB & 4)
@@ -224,12 +249,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
                 lo = *reinterpret_cast<const f32x4 *>(rp) + lo;
                 hi = *reinterpret_cast<const f32x4 *>(rp + 4) + hi;
             }
-            if (OUTK == OUT_P3) {
+            if (LAB & 64) {   /* keep the values alive, store nothing */
+                asm volatile("" ::"v"(lo), "v"(hi));
+            } else if (OUTK == OUT_PLANES) {
                 frag_t part[3];
-                split8(lo, hi, part[0], part[1], part[2]);
-                char *dst = static_cast<char *>(p.C) + ((size_t)((n0 >> 5) + s) * 3 * p.a_rows + row) * 64 + 16 * q;
+                if (NPL == 3) {
+                    split8(lo, hi, part[0], part[1], part[2]);
+                } else {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                    for (int e = 0; e < 8; ++e)
+                        part[0][e] = (__bf16)(e < 4 ? lo[e] : hi[e - 4]);
+                }
+                char *dst = static_cast<char *>(p.C) + ((size_t)((n0 >> 5) + s) * NPL * p.a_rows + row) * 64 + 16 * q;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
                     *reinterpret_cast<f32x4 *>(dst + pl * a_plane) = __builtin_bit_cast(f32x4, part[pl]);
             } else {
                 float *cp = static_cast<float *>(p.C) + (size_t)row * p.N + col;
@@ -240,14 +273,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
     }
 }
 
-template <int NW, int BN, int EPI, int OUTK>
+template <int NW, int BN, int EPI, int OUTK, int NPL>
 int launch_p3_tile(hipStream_t st, P3Params p)
 {
-    constexpr int LDS = 2 * 3 * BN * 64;
-    VH_SET_LDS_ONCE((gemm_p3_kernel<NW, BN, EPI, OUTK>), LDS);
+    constexpr int LDS = 2 * (NPL == 3 ? 1 : 2) * NPL * BN * 64;
+    VH_SET_LDS_ONCE((gemm_p3_kernel<NW, BN, EPI, OUTK, NPL>), LDS);
     p.mtiles = (p.row_end - p.row_begin + 32 * NW - 1) / (32 * NW);
     p.ntiles = p.N / BN;
-    hipLaunchKernelGGL((gemm_p3_kernel<NW, BN, EPI, OUTK>), dim3(p.mtiles * p.ntiles), dim3(64 * NW), LDS, st, p);
+    hipLaunchKernelGGL((gemm_p3_kernel<NW, BN, EPI, OUTK, NPL>), dim3(p.mtiles * p.ntiles), dim3(64 * NW), LDS, st, p);
     VH_LAUNCH_CHECK("gemm_p3_kernel");
     return 0;
 }
@@ -260,7 +293,7 @@ int launch_p3_tile(hipStream_t st, P3Params p)
  * 128x128 tile alone: at equal work it is within 3 % of the big tile, and it quantises four times finer
  * (batch 64: 5495 against 4947 images/s).  Every tile computes the same k order: results do not depend on
  * the choice. */
-template <int EPI, int OUTK>
+template <int EPI, int OUTK, int NPL>
 int launch_p3(hipStream_t st, const P3Params &p, int small_only)
 {
     const int rows = p.row_end - p.row_begin;
@@ -268,20 +301,22 @@ int launch_p3(hipStream_t st, const P3Params &p, int small_only)
     const int ntiles = p.N / 256, mtiles = (rows + 255) / 256;
     const long tiles = (long)mtiles * ntiles;
     if (p.N % 256 != 0 || small_only || 2 * tiles < 5 * (long)num_cus)
-        return launch_p3_tile<4, 128, EPI, OUTK>(st, p);
+        return launch_p3_tile<4, 128, EPI, OUTK, NPL>(st, p);
     const long full = tiles / num_cus, rem = tiles % num_cus;
     const int rows_big = (int)(full * num_cus / ntiles) * 256;
+    auto big_tiles = [&](const P3Params &q) { return launch_p3_tile<8, 256, EPI, OUTK, NPL>(st, q); };
     if (rem == 0 || 4 * rem > 3 * num_cus || rows_big <= 0 || rows_big >= rows)
-        return launch_p3_tile<8, 256, EPI, OUTK>(st, p);
+        return big_tiles(p);
     P3Params big = p, rest = p;
     big.row_end = p.row_begin + rows_big;
     rest.row_begin = big.row_end;
-    const int rc = launch_p3_tile<8, 256, EPI, OUTK>(st, big);
-    return rc ? rc : launch_p3_tile<4, 128, EPI, OUTK>(st, rest);
+    const int rc = big_tiles(big);
+    return rc ? rc : launch_p3_tile<4, 128, EPI, OUTK, NPL>(st, rest);
 }
 
-/* fp32 [rows][K] <-> planes [K/32][3][rows][32]: one thread per 8 consecutive elements */
-__global__ void split3_rows_kernel(const float *__restrict__ in, char *__restrict__ planes, int rows, int K)
+/* fp32 [rows][K] <-> planes [K/32][NPL][rows][32]: one thread per 8 consecutive elements */
+template <int NPL>
+__global__ void split_rows_kernel(const float *__restrict__ in, char *__restrict__ planes, int rows, int K)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int k8 = K >> 3;
@@ -289,70 +324,104 @@ __global__ void split3_rows_kernel(const float *__restrict__ in, char *__restric
         return;
     const int row = (int)(idx / k8), c8 = (int)(idx - (size_t)row * k8);
     const float *src = in + (size_t)row * K + 8 * c8;
+    const f32x4 u = *reinterpret_cast<const f32x4 *>(src), v = *reinterpret_cast<const f32x4 *>(src + 4);
     bf16x8 part[3];
-    split8(*reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4), part[0], part[1], part[2]);
-    char *dst = planes + ((size_t)(c8 >> 2) * 3 * rows + row) * 64 + 16 * (c8 & 3);
+    if (NPL == 3) {
+        split8(u, v, part[0], part[1], part[2]);
+    } else {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+        for (int e = 0; e < 8; ++e)
+            part[0][e] = (__bf16)(e < 4 ? u[e] : v[e - 4]);
+    }
+    char *dst = planes + ((size_t)(c8 >> 2) * NPL * rows + row) * 64 + 16 * (c8 & 3);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
         *reinterpret_cast<f32x4 *>(dst + (size_t)pl * rows * 64) = __builtin_bit_cast(f32x4, part[pl]);
 }
 
-__global__ void merge3_rows_kernel(const char *__restrict__ planes, float *__restrict__ out, int rows, int K)
+template <int NPL>
+__global__ void merge_rows_kernel(const char *__restrict__ planes, float *__restrict__ out, int rows, int K)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int k8 = K >> 3;
     if (idx >= (size_t)rows * k8)
         return;
     const int row = (int)(idx / k8), c8 = (int)(idx - (size_t)row * k8);
-    const char *src = planes + ((size_t)(c8 >> 2) * 3 * rows + row) * 64 + 16 * (c8 & 3);
+    const char *src = planes + ((size_t)(c8 >> 2) * NPL * rows + row) * 64 + 16 * (c8 & 3);
     bf16x8 part[3];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
         part[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(src + (size_t)pl * rows * 64));
     float *dst = out + (size_t)row * K + 8 * c8;
 #pragma unroll
     for (int e = 0; e < 8; ++e)   /* exact: the parts are disjoint slices of one 24-bit significand */
-        dst[e] = ((float)part[0][e] + (float)part[1][e]) + (float)part[2][e];
+        dst[e] = NPL == 3 ? ((float)part[0][e] + (float)part[1][e]) + (float)part[2][e] : (float)part[0][e];
+}
+
+int check_planes_args(const char *who, const void *a, const void *b, int rows, int cols, int parts)
+{
+    if (!a || !b || rows <= 0 || cols <= 0 || cols % 32 != 0 || (((uintptr_t)a | (uintptr_t)b) & 15) || (parts != 1 && parts != 3))
+        return vh_fail(1, "%s: bad argument (cols %% 32 == 0, 16-byte aligned pointers, parts 1 or 3)", who);
+    return 0;
 }
 
 } // namespace
 
+extern "C" int vh_launch_split_rows(vh_stream_t s, const float *input, void *planes, int rows, int cols, int parts)
+{
+    if (int rc = check_planes_args("vh_launch_split_rows", input, planes, rows, cols, parts))
+        return rc;
+    const size_t threads = (size_t)rows * (cols / 8);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (parts == 3)
+        hipLaunchKernelGGL(split_rows_kernel<3>, grid, dim3(256), 0, (hipStream_t)s, input, static_cast<char *>(planes), rows, cols);
+    else
+        hipLaunchKernelGGL(split_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)s, input, static_cast<char *>(planes), rows, cols);
+    VH_LAUNCH_CHECK("split_rows_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_merge_rows(vh_stream_t s, const void *planes, float *output, int rows, int cols, int parts)
+{
+    if (int rc = check_planes_args("vh_launch_merge_rows", planes, output, rows, cols, parts))
+        return rc;
+    const size_t threads = (size_t)rows * (cols / 8);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (parts == 3)
+        hipLaunchKernelGGL(merge_rows_kernel<3>, grid, dim3(256), 0, (hipStream_t)s, static_cast<const char *>(planes), output, rows, cols);
+    else
+        hipLaunchKernelGGL(merge_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)s, static_cast<const char *>(planes), output, rows, cols);
+    VH_LAUNCH_CHECK("merge_rows_kernel");
+    return 0;
+}
+
 extern "C" int vh_launch_split3_rows(vh_stream_t s, const float *input, void *planes, int rows, int cols)
 {
-    if (!input || !planes || rows <= 0 || cols <= 0 || cols % 32 != 0 || (((uintptr_t)input | (uintptr_t)planes) & 15))
-        return vh_fail(1, "vh_launch_split3_rows: bad argument (cols %% 32 == 0, 16-byte aligned pointers)");
-    const size_t threads = (size_t)rows * (cols / 8);
-    hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, input,
-                       static_cast<char *>(planes), rows, cols);
-    VH_LAUNCH_CHECK("split3_rows_kernel");
-    return 0;
+    return vh_launch_split_rows(s, input, planes, rows, cols, 3);
 }
 
 extern "C" int vh_launch_merge3_rows(vh_stream_t s, const void *planes, float *output, int rows, int cols)
 {
-    if (!output || !planes || rows <= 0 || cols <= 0 || cols % 32 != 0 || (((uintptr_t)output | (uintptr_t)planes) & 15))
-        return vh_fail(1, "vh_launch_merge3_rows: bad argument (cols %% 32 == 0, 16-byte aligned pointers)");
-    const size_t threads = (size_t)rows * (cols / 8);
-    hipLaunchKernelGGL(merge3_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s,
-                       static_cast<const char *>(planes), output, rows, cols);
-    VH_LAUNCH_CHECK("merge3_rows_kernel");
-    return 0;
+    return vh_launch_merge_rows(s, planes, output, rows, cols, 3);
 }
 
-extern "C" int vh_launch_linear_p3(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
-                                   const void *input_planes, const float *bias, int rowA, int colA, int colB,
-                                   int doGelu, const float *residual)
+extern "C" int vh_launch_linear_planes(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
+                                       const void *input_planes, int parts, const float *bias, int rowA, int colA,
+                                       int colB, int doGelu, const float *residual)
 {
     if (!output || !weight_planes || !input_planes || !bias)
-        return vh_fail(1, "vh_launch_linear_p3: null pointer argument");
-    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % 64 != 0 || colB % 128 != 0)
-        return vh_fail(1, "vh_launch_linear_p3: needs colA %% 64 == 0 and colB %% 128 == 0 (%d,%d,%d)", rowA, colA, colB);
+        return vh_fail(1, "vh_launch_linear_planes: null pointer argument");
+    if (parts != 1 && parts != 3)
+        return vh_fail(1, "vh_launch_linear_planes: parts must be 3 (exact fp32 split) or 1 (bf16 operands)");
+    const int kstep = parts == 3 ? 64 : 128;   /* two LDS stages per loop iteration */
+    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % kstep != 0 || colB % 128 != 0)
+        return vh_fail(1, "vh_launch_linear_planes: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", kstep, rowA, colA, colB);
     if ((doGelu && residual) || (residual && output_planes))
-        return vh_fail(1, "vh_launch_linear_p3: unsupported epilogue combination");
+        return vh_fail(1, "vh_launch_linear_planes: unsupported epilogue combination");
     if ((((uintptr_t)output | (uintptr_t)weight_planes | (uintptr_t)input_planes | (uintptr_t)bias | (uintptr_t)residual) & 15) != 0)
-        return vh_fail(1, "vh_launch_linear_p3: pointers must be 16-byte aligned");
+        return vh_fail(1, "vh_launch_linear_planes: pointers must be 16-byte aligned");
     if ((size_t)rowA * 64 > 0xffffffffull)
-        return vh_fail(1, "vh_launch_linear_p3: rowA=%d too large", rowA);
+        return vh_fail(1, "vh_launch_linear_planes: rowA=%d too large", rowA);
     P3Params p = {};
     p.A = static_cast<const char *>(input_planes);
     p.W = static_cast<const char *>(weight_planes);
@@ -366,9 +435,26 @@ extern "C" int vh_launch_linear_p3(vh_stream_t s, void *output, int output_plane
         force_small = (env && env[0] == '1') ? 1 : 0;
     }
     const int small_only = force_small || (residual && colA < 2048);   /* the N = K = E output projection: measured */
-    if (doGelu)
-        return output_planes ? launch_p3<EPI_GELU, OUT_P3>(st, p, small_only) : launch_p3<EPI_GELU, OUT_F32>(st, p, small_only);
-    if (residual)
-        return launch_p3<EPI_RESID, OUT_F32>(st, p, small_only);
-    return output_planes ? launch_p3<EPI_NONE, OUT_P3>(st, p, small_only) : launch_p3<EPI_NONE, OUT_F32>(st, p, small_only);
+#define VH_P3_DISPATCH(NPL)                                                                                          \
+    do {                                                                                                             \
+        if (doGelu)                                                                                                  \
+            return output_planes ? launch_p3<EPI_GELU, OUT_PLANES, NPL>(st, p, small_only)                           \
+                                 : launch_p3<EPI_GELU, OUT_F32, NPL>(st, p, small_only);                             \
+        if (residual)                                                                                                \
+            return launch_p3<EPI_RESID, OUT_F32, NPL>(st, p, small_only);                                            \
+        return output_planes ? launch_p3<EPI_NONE, OUT_PLANES, NPL>(st, p, small_only)                               \
+                             : launch_p3<EPI_NONE, OUT_F32, NPL>(st, p, small_only);                                 \
+    } while (0)
+    if (parts == 3)
+        VH_P3_DISPATCH(3);
+    VH_P3_DISPATCH(1);
+#undef VH_P3_DISPATCH
+}
+
+extern "C" int vh_launch_linear_p3(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
+                                   const void *input_planes, const float *bias, int rowA, int colA, int colB,
+                                   int doGelu, const float *residual)
+{
+    return vh_launch_linear_planes(s, output, output_planes, weight_planes, input_planes, 3, bias, rowA, colA, colB,
+                                   doGelu, residual);
 }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
  * planes' own order, [K step][part][16 rows][64 B], so that every global store instruction writes one
  * contiguous, aligned KiB (16 rows x 64 B of one K step and part) instead of eight 64-byte pieces 19 MB apart. */
 constexpr int LN3_ROWS = 16;
-template <int NV>
+template <int NV, int NPL>   /* NPL parts per value: 3 = exact split, 1 = rounded to bf16 (the bf16-operand mode) */
 __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float *__restrict__ in,
                                                                     const float *__restrict__ gamma,
                                                                     const float *__restrict__ beta,
@@ -146,17 +146,20 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float
                 for (int e = 0; e < 4; ++e)
                     y[e] = (x[c][e] - mean) * inv_std * g[e] + bb[e];
                 bf16x4 part[3];
-                split4(y, part[0], part[1], part[2]);
-                char *d = ln_lds + ((size_t)(idx >> 3) * 3 * LN3_ROWS + wave) * 64 + 8 * (idx & 7);
+                if (NPL == 3)
+                    split4(y, part[0], part[1], part[2]);
+                else
+                    part[0] = bf16x4{(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+                char *d = ln_lds + ((size_t)(idx >> 3) * NPL * LN3_ROWS + wave) * 64 + 8 * (idx & 7);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NPL; ++pl)
                     *reinterpret_cast<bf16x4 *>(d + pl * LN3_ROWS * 64) = part[pl];
             }
         }
     }
     __syncthreads();
     /* copy-out: piece = (K step, part) = 1 KiB = 16 rows x 64 B; lane l moves 16 bytes of row l / 4 */
-    const int pieces = (E >> 5) * 3;
+    const int pieces = (E >> 5) * NPL;
     if (row0 + (lane >> 2) < rows)
         for (int pc = wave; pc < pieces; pc += LN3_ROWS)
             *reinterpret_cast<f32x4 *>(planes + ((size_t)pc * rows + row0) * 64 + 16 * lane) =
@@ -262,32 +265,49 @@ extern "C" int vh_launch_layer_norm_bf16(vh_stream_t s, const float *input, cons
                              out_row_stride, eps);
 }
 
-extern "C" int vh_launch_layer_norm_p3(vh_stream_t s, const float *input, const float *weight, const float *bias,
-                                       void *out_planes, int rows, int embed_dim, long in_row_stride, double eps)
+extern "C" int vh_launch_layer_norm_planes(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                                           void *out_planes, int parts, int rows, int embed_dim, long in_row_stride,
+                                           double eps)
 {
     if (!input || !weight || !bias || !out_planes)
-        return vh_fail(1, "vh_launch_layer_norm_p3: null pointer argument");
-    if (rows <= 0 || embed_dim <= 0 || embed_dim % 32 != 0 || embed_dim > 2048 || ((uintptr_t)out_planes & 15))
-        return vh_fail(1, "vh_launch_layer_norm_p3: embed_dim=%d must be a multiple of 32, <= 2048, planes 16-byte aligned", embed_dim);
+        return vh_fail(1, "vh_launch_layer_norm_planes: null pointer argument");
+    if (rows <= 0 || embed_dim <= 0 || embed_dim % 32 != 0 || embed_dim > 2048 || ((uintptr_t)out_planes & 15) ||
+        (parts != 1 && parts != 3))
+        return vh_fail(1, "vh_launch_layer_norm_planes: embed_dim=%d must be a multiple of 32, <= 2048, planes 16-byte "
+                          "aligned, parts 1 or 3", embed_dim);
     if (in_row_stride % 4 != 0 || in_row_stride < embed_dim)
-        return vh_fail(1, "vh_launch_layer_norm_p3: row stride must be a multiple of 4 floats and >= embed_dim");
+        return vh_fail(1, "vh_launch_layer_norm_planes: row stride must be a multiple of 4 floats and >= embed_dim");
     const int nv = (embed_dim / 4 + 63) / 64;
-    const size_t lds = (size_t)(embed_dim / 32) * 3 * LN3_ROWS * 64;
+    const size_t lds = (size_t)(embed_dim / 32) * parts * LN3_ROWS * 64;
     const dim3 grid((rows + LN3_ROWS - 1) / LN3_ROWS), block(64 * LN3_ROWS);
     hipStream_t st = (hipStream_t)s;
+#define VH_LN3_K(NV, NPL)                                                                                 \
+    do {                                                                                                  \
+        VH_SET_LDS_ONCE((layernorm_p3_kernel<NV, NPL>), 160 * 1024);                                      \
+        hipLaunchKernelGGL((layernorm_p3_kernel<NV, NPL>), grid, block, lds, st, input, weight, bias,     \
+                           static_cast<char *>(out_planes), rows, embed_dim, in_row_stride, eps);         \
+    } while (0)
 #define VH_LN3(NV)                                                                                        \
     do {                                                                                                  \
-        VH_SET_LDS_ONCE((layernorm_p3_kernel<NV>), 160 * 1024);                                           \
-        hipLaunchKernelGGL((layernorm_p3_kernel<NV>), grid, block, lds, st, input, weight, bias,          \
-                           static_cast<char *>(out_planes), rows, embed_dim, in_row_stride, eps);         \
+        if (parts == 3)                                                                                   \
+            VH_LN3_K(NV, 3);                                                                              \
+        else                                                                                              \
+            VH_LN3_K(NV, 1);                                                                              \
     } while (0)
     if (nv <= 3) VH_LN3(3);
     else if (nv <= 4) VH_LN3(4);
     else if (nv <= 5) VH_LN3(5);
     else VH_LN3(8);
 #undef VH_LN3
+#undef VH_LN3_K
     VH_LAUNCH_CHECK("layernorm_p3_kernel");
     return 0;
+}
+
+extern "C" int vh_launch_layer_norm_p3(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                                       void *out_planes, int rows, int embed_dim, long in_row_stride, double eps)
+{
+    return vh_launch_layer_norm_planes(s, input, weight, bias, out_planes, 3, rows, embed_dim, in_row_stride, eps);
 }
 
 extern "C" int vh_launch_layer_norm_fp8(vh_stream_t s, const float *input, const float *weight,
