@@ -149,7 +149,7 @@ int vh_launch_merge_rows(vh_stream_t s, const void *planes, float *output, int r
 int vh_launch_layer_norm_planes(vh_stream_t s, const float *input, const float *weight, const float *bias,
                                 void *out_planes, int parts, int rows, int embed_dim, long in_row_stride, double eps);
 int vh_launch_attention_planes_bf16(vh_stream_t s, const float *qkv, void *out_planes, int n_images, int tokens,
-                                    int embed_dim, int num_heads);   /* one-part planes, arithmetic of vh_launch_attention_bf16 */
+                                    int embed_dim, int num_heads);   /* one-part planes, arithmetic of vh_launch_attention_f16 */
 /* colA % 64 == 0 (parts 3) or % 128 == 0 (parts 1); fp32 accumulation, bias, GELU, residual as vh_launch_linear */
 int vh_launch_linear_planes(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
                             const void *input_planes, int parts, const float *bias, int rowA, int colA, int colB,
@@ -195,24 +195,10 @@ int vh_launch_attention(vh_stream_t s, const float *qkv, float *output, int n_im
  * ViT_seq.c:372. */
 int vh_launch_softmax(vh_stream_t s, const float *input, float *output, int rows, int length);
 
-/* ---- bf16-operand variants (BASELINE config 3: "bf16 ... MFMA QKV/MLP GEMMs") ----
- * No reference counterpart (the reference is fp32 throughout).  GEMM operands are bf16
- * with fp32 accumulation; the residual stream, biases, LayerNorm statistics, the
- * attention arithmetic and the classifier stay fp32.  A producer whose only consumer
- * is a bf16 GEMM rounds to bf16 when it stores (identical to rounding at the GEMM's
- * input, half the bytes): LayerNorm output, attention output, the MLP hidden layer. */
-int vh_launch_convert_bf16(vh_stream_t s, const float *input, void *output, size_t count);
-int vh_launch_layer_norm_bf16(vh_stream_t s, const float *input, const float *weight,
-                              const float *bias, void *output, int rows, int embed_dim,
-                              long in_row_stride, long out_row_stride, double eps);
-/* output (fp32, or bf16 when output_bf16) = input_bf16 . weight_bf16^T + bias [+GELU | +residual] */
-int vh_launch_linear_bf16(vh_stream_t s, void *output, int output_bf16, const void *weight,
-                          const void *input, const float *bias, int rowA, int colA, int colB,
-                          int doGelu, const float *residual);
-int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *output, int n_images,
-                             int tokens, int embed_dim, int num_heads);
-/* In these modes the attention's two products run on fp16-rounded Q, K, V and P (11-bit operands, fp32
- * accumulation and softmax; far inside the modes' tolerances); _bf16 writes bf16, _f16 writes fp32. */
+/* ---- reduced-precision attention (the bf16- and fp8-operand modes, BASELINE configs 3 and 5) ----
+ * fp32 in, fp32 out; Q, K, V and P rounded to fp16 for the two products (11-bit operands, fp32 accumulation and
+ * softmax): far inside those modes' tolerances.  The bf16-operand mode itself runs on one-part planes:
+ * vh_launch_layer_norm_planes / vh_launch_attention_planes_bf16 / vh_launch_linear_planes with parts = 1 (above). */
 int vh_launch_attention_f16(vh_stream_t s, const float *qkv, float *output, int n_images,
                             int tokens, int embed_dim, int num_heads);
 

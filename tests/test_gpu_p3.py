@@ -280,22 +280,20 @@ def test_linear_planes_one_part_vs_oracle_on_bf16_rounded_operands(pkg, device, 
     assert np.abs(got[rows] - want).max() <= tol
 
 
-def test_layer_norm_and_attention_one_part_planes_equal_their_bf16_twins(pkg, device, oracle, weights):
-    """vh_launch_layer_norm_planes(parts = 1) and vh_launch_attention_planes_bf16 write the values of
-    vh_launch_layer_norm_bf16 / vh_launch_attention_bf16 (row-major bf16), in plane order."""
+def test_layer_norm_and_attention_one_part_planes_are_the_rounded_fp32_results(pkg, device, oracle, weights):
+    """vh_launch_layer_norm_planes(parts = 1) writes vh_launch_layer_norm's values rounded to bf16 (nearest even),
+    vh_launch_attention_planes_bf16 those of vh_launch_attention_f16 (the reduced modes' attention), in plane order."""
     rows, E, H = 1000, 768, 12
     x = oracle.synth_fill(rows * E, 31, 3.0, 0.5).reshape(rows, E)
     d_x, d_g, d_b = _dev(pkg, x), _dev(pkg, weights[4]), _dev(pkg, weights[5])
-    d_y16, d_p1 = pkg.DeviceBuffer(rows * E // 2), pkg.DeviceBuffer(rows * E // 2)
-    _launch(pkg, "vh_launch_layer_norm_bf16", None, d_x.ptr, d_g.ptr, d_b.ptr, d_y16.ptr, rows, E, E, E, 1e-6)
+    d_y, d_p1 = pkg.DeviceBuffer(rows * E), pkg.DeviceBuffer(rows * E // 2)
+    _launch(pkg, "vh_launch_layer_norm", None, d_x.ptr, d_g.ptr, d_b.ptr, d_y.ptr, rows, E, E, E, 1e-6)
     _launch(pkg, "vh_launch_layer_norm_planes", None, d_x.ptr, d_g.ptr, d_b.ptr, d_p1.ptr, 1, rows, E, E, 1e-6)
-    twin = (d_y16.to_numpy().view(np.uint16)[:rows * E].astype(np.uint32) << 16).view(np.float32).reshape(rows, E)
-    assert np.array_equal(_planes1_to_f32(d_p1, rows, E), twin)
+    assert np.array_equal(_planes1_to_f32(d_p1, rows, E), _bf16_rne(d_y.to_numpy((rows, E))))
     n_images, tokens = 3, 197
     rows = n_images * tokens
     qkv = oracle.synth_fill(rows * 3 * E, 78, 1.0, 0.0)
-    d_q, d_o16, d_o1 = _dev(pkg, qkv), pkg.DeviceBuffer(rows * E // 2 + 1), pkg.DeviceBuffer(rows * E // 2 + 1)
-    _launch(pkg, "vh_launch_attention_bf16", None, d_q.ptr, d_o16.ptr, n_images, tokens, E, H)
+    d_q, d_o, d_o1 = _dev(pkg, qkv), pkg.DeviceBuffer(rows * E), pkg.DeviceBuffer(rows * E // 2 + 1)
+    _launch(pkg, "vh_launch_attention_f16", None, d_q.ptr, d_o.ptr, n_images, tokens, E, H)
     _launch(pkg, "vh_launch_attention_planes_bf16", None, d_q.ptr, d_o1.ptr, n_images, tokens, E, H)
-    twin = (d_o16.to_numpy().view(np.uint16)[:rows * E].astype(np.uint32) << 16).view(np.float32).reshape(rows, E)
-    assert np.array_equal(_planes1_to_f32(d_o1, rows, E), twin)
+    assert np.array_equal(_planes1_to_f32(d_o1, rows, E), _bf16_rne(d_o.to_numpy((rows, E))))

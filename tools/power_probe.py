@@ -118,19 +118,19 @@ def main():
     a16, w16 = pkg.DeviceBuffer(M * K // 2), pkg.DeviceBuffer(N * K // 2)
     stream = C.c_void_p()
     pkg.binding.check(lib.vh_stream_create(C.byref(stream)), "stream")
-    pkg.binding.check(lib.vh_launch_convert_bf16(stream, a.ptr, a16.ptr, M * K), "cvt")
-    pkg.binding.check(lib.vh_launch_convert_bf16(stream, w.ptr, w16.ptr, N * K), "cvt")
+    pkg.binding.check(lib.vh_launch_split_rows(stream, a.ptr, a16.ptr, M, K, 1), "planes")     # one-part (bf16) planes
+    pkg.binding.check(lib.vh_launch_split_rows(stream, w.ptr, w16.ptr, N, K, 1), "planes")
     print(f"power sources: {sysfs_sources() or 'rocm-smi'}", flush=True)
 
     def f32():
         pkg.binding.check(lib.vh_launch_linear(stream, out.ptr, w.ptr, a.ptr, b.ptr, M, K, N, 1, None), "linear")
 
     def b16():
-        pkg.binding.check(lib.vh_launch_linear_bf16(stream, out.ptr, 0, w16.ptr, a16.ptr, b.ptr, M, K, N, 1, None),
-                  "linear_bf16")
+        pkg.binding.check(lib.vh_launch_linear_planes(stream, out.ptr, 0, w16.ptr, a16.ptr, 1, b.ptr, M, K, N, 1, None),
+                  "linear_planes")
 
     leg("idle", lambda: time.sleep(0.01), lib, stream)
-    leg("fp32 (" + os.environ.get("VIT_HIP_GEMM_FP32", "split3") + ", mfma " + os.environ.get("VIT_HIP_GEMM_MFMA", "16") + ")", f32, lib, stream)
+    leg("fp32 (" + os.environ.get("VIT_HIP_GEMM_FP32", "split3") + ", split in the K loop)", f32, lib, stream)
     leg("bf16 operands", b16, lib, stream)
 
 

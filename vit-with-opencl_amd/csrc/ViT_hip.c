@@ -223,6 +223,8 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
         return 2;
     if (precision == VIT_PRECISION_FP8_GEMM && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
         return 2;
+    if (precision == VIT_PRECISION_BF16_GEMM && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
+        return 2;
     *out = NULL;
     if (n_tensors != vit_config_num_tensors(cfg))
         return 2;
@@ -296,17 +298,14 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
             for (int k = 0; k < 4; ++k) {
                 const int idx = 4 + 12 * l + big[k];
                 ctx->w16[idx] = (char *)ctx->w16_slab + off16;
-                if (cfg->embed_dim % 128 == 0 && cfg->mlp_hidden % 128 == 0)   /* one-part planes [K/32][1][N][32] (gemm_p3.hip) */
-                    TRY(vh_launch_split_rows(ctx->stream, ctx->w[idx], ctx->w16[idx], (int)networks[idx + 1].size,
-                                             (int)(networks[idx].size / networks[idx + 1].size), 1));
-                else
-                    TRY(vh_launch_convert_bf16(ctx->stream, ctx->w[idx], ctx->w16[idx], networks[idx].size));
+                /* one-part planes [K/32][1][N][32] (gemm_p3.hip) */
+                TRY(vh_launch_split_rows(ctx->stream, ctx->w[idx], ctx->w16[idx], (int)networks[idx + 1].size,
+                                         (int)(networks[idx].size / networks[idx + 1].size), 1));
                 off16 += align_up(networks[idx].size * 2, 256);
             }
     }
 
-    const char *env_w3 = getenv("VIT_HIP_W3");
-    if (precision == VIT_PRECISION_F32 && !(env_w3 && env_w3[0] == '0') && cfg->embed_dim % 128 == 0 &&
+    if (precision == VIT_PRECISION_F32 && cfg->embed_dim % 128 == 0 &&
         cfg->mlp_hidden % 128 == 0) {
         /* the constant GEMM operand split once (exact 3-way bf16 split, 6 bytes per weight) */
         static const int big[4] = {2, 4, 8, 10};
@@ -485,8 +484,7 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         OP(VIT_OP_FC1, vh_launch_linear_h2(s, ctx->hid, l3[8], ws[8], ctx->y, lw[9], rows, E, F, 1, NULL));
         OP(VIT_OP_FC2, vh_launch_linear_h2(s, ctx->x, l3[10], ws[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
     }
-    const int bf16_planes = E % 128 == 0 && F % 128 == 0 && (size_t)rows * 64 <= 0xffffffffull;
-    for (int l = 0; l < c->depth && mode == VIT_PRECISION_BF16_GEMM && bf16_planes; ++l) {
+    for (int l = 0; l < c->depth && mode == VIT_PRECISION_BF16_GEMM; ++l) {
         /* bf16 GEMM operands as one-part planes [K/32][1][rows][32], written by their producers; the same
          * kernel as the fp32 path with one product per block (gemm_p3.hip, NPL = 1) */
         float **lw = w + 4 + 12 * l;
@@ -502,19 +500,6 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_planes(s, ctx->x, lw[6], lw[7], ctx->y, 1, rows, E, E, c->eps));
         OP(VIT_OP_FC1, vh_launch_linear_planes(s, ctx->hid, 1, lw16[8], ctx->y, 1, lw[9], rows, E, F, 1, NULL));
         OP(VIT_OP_FC2, vh_launch_linear_planes(s, ctx->x, 0, lw16[10], ctx->hid, 1, lw[11], rows, F, E, 0, ctx->x));
-    }
-    for (int l = 0; l < c->depth && mode == VIT_PRECISION_BF16_GEMM && !bf16_planes; ++l) {
-        /* bf16 GEMM operands: y, attn and hid hold bf16 (same allocations, half used);
-         * the residual stream x, the fused qkv and all statistics stay fp32 */
-        float **lw = w + 4 + 12 * l;
-        void **lw16 = ctx->w16 + 4 + 12 * l;
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_bf16(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
-        OP(VIT_OP_QKV, vh_launch_linear_bf16(s, ctx->qkv, 0, lw16[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
-        OP(VIT_OP_ATTENTION, vh_launch_attention_bf16(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-        OP(VIT_OP_OUT_PROJ, vh_launch_linear_bf16(s, ctx->x, 0, lw16[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_bf16(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
-        OP(VIT_OP_FC1, vh_launch_linear_bf16(s, ctx->hid, 1, lw16[8], ctx->y, lw[9], rows, E, F, 1, NULL));
-        OP(VIT_OP_FC2, vh_launch_linear_bf16(s, ctx->x, 0, lw16[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
     }
     for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32 && ctx->use_p3; ++l) {
         /* GEMM inputs as pre-split planes: LayerNorm, attention and the fc1 epilogue write them */
@@ -740,9 +725,6 @@ static void gather_images(float *dst, const ImageData *images, int m, size_t img
     int nt = m / 16;
     if (nt > MAX_THREADS)
         nt = MAX_THREADS;
-    const char *env = getenv("VIT_HIP_GATHER_THREADS");
-    if (env && atoi(env) > 0)
-        nt = atoi(env) < MAX_THREADS ? atoi(env) : MAX_THREADS;
     struct gather_job jobs[MAX_THREADS];
     pthread_t tid[MAX_THREADS];
     int started = 0;

@@ -393,12 +393,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float *__
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-                    if (OUTK == 1) { /* consumed only by the bf16-operand output projection */
-                        bf16x4 v16 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        *reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(out) + off + dt * 32 + 8 * g) = v16;
-                    } else {
-                        *reinterpret_cast<f32x4 *>(static_cast<float *>(out) + off + dt * 32 + 8 * g) = v;
-                    }
+                    *reinterpret_cast<f32x4 *>(static_cast<float *>(out) + off + dt * 32 + 8 * g) = v;
                 }
         }
 
@@ -427,25 +422,21 @@ int launch_k(hipStream_t st, const float *qkv, void *out, int n_images, int T, i
 }
 
 /* arith: 0 = fp32 MFMA, 3 = exact three-part bf16 split (default), 2 = two fp16 parts (emulation mode),
- * 1 = operands rounded to fp16 (the bf16 / fp8 GEMM modes) */
+ * 1 = operands rounded to fp16 (the bf16 / fp8 GEMM modes).  out_kind: 0 = fp32 rows, 3 = three-part planes
+ * (exact split), 4 = one-part (bf16) planes. */
 template <int NKT>
-int launch(hipStream_t st, const float *qkv, void *out, int out_bf16, int arith, int n_images, int T, int E, int H)
+int launch(hipStream_t st, const float *qkv, void *out, int out_kind, int arith, int n_images, int T, int E, int H)
 {
-    if (out_bf16 == 3)   /* planes for the pre-split output projection (exact split only) */
+    if (out_kind == 3)
         return launch_k<NKT, 3, 3>(st, qkv, out, n_images, T, E, H);
-    if (out_bf16 == 4)   /* one-part (bf16) planes; products on fp16-rounded operands like the other reduced modes */
-        return arith == 1 ? launch_k<NKT, 4, 1>(st, qkv, out, n_images, T, E, H)
-                          : launch_k<NKT, 4, 3>(st, qkv, out, n_images, T, E, H);
-    if (arith == 2 && !out_bf16)
-        return launch_k<NKT, false, 2>(st, qkv, out, n_images, T, E, H);
-    if (arith == 1)
-        return out_bf16 ? launch_k<NKT, true, 1>(st, qkv, out, n_images, T, E, H)
-                        : launch_k<NKT, false, 1>(st, qkv, out, n_images, T, E, H);
-    if (arith == 0)
-        return out_bf16 ? launch_k<NKT, true, 0>(st, qkv, out, n_images, T, E, H)
-                        : launch_k<NKT, false, 0>(st, qkv, out, n_images, T, E, H);
-    return out_bf16 ? launch_k<NKT, true, 3>(st, qkv, out, n_images, T, E, H)
-                    : launch_k<NKT, false, 3>(st, qkv, out, n_images, T, E, H);
+    if (out_kind == 4)
+        return launch_k<NKT, 4, 1>(st, qkv, out, n_images, T, E, H);
+    switch (arith) {
+    case 0: return launch_k<NKT, 0, 0>(st, qkv, out, n_images, T, E, H);
+    case 1: return launch_k<NKT, 0, 1>(st, qkv, out, n_images, T, E, H);
+    case 2: return launch_k<NKT, 0, 2>(st, qkv, out, n_images, T, E, H);
+    default: return launch_k<NKT, 0, 3>(st, qkv, out, n_images, T, E, H);
+    }
 }
 
 } // namespace
@@ -469,10 +460,10 @@ static int launch_attention(vh_stream_t s, const float *qkv, void *output, int o
         return vh_attention_tiled(s, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
     static int native = -1;
     if (native < 0) {
-        const char *env = getenv("VIT_HIP_ATTN_MFMA");   /* "fp32": the fp32 matrix instruction */
-        native = (env && env[0] == 'f') ? 1 : 0;
+        const char *env = getenv("VIT_HIP_GEMM_FP32");   /* "native": the fp32 matrix instruction here too */
+        native = (env && env[0] == 'n') ? 1 : 0;
     }
-    if (native && arith == 3)
+    if (native && arith == 3 && out_bf16 == 0)
         arith = 0;
     hipStream_t st = (hipStream_t)s;
     switch ((tokens + 31) / 32) {
@@ -492,18 +483,6 @@ extern "C" int vh_launch_attention(vh_stream_t s, const float *qkv, float *outpu
     return launch_attention(s, qkv, output, 0, 3, n_images, tokens, embed_dim, num_heads);
 }
 
-extern "C" int vh_launch_attention_bf16(vh_stream_t s, const float *qkv, void *output, int n_images,
-                                        int tokens, int embed_dim, int num_heads)
-{
-    /* the bf16-operand GEMM mode: Q, K, V, P rounded to fp16 for the two products (VIT_HIP_ATTN_LOWP=0: exact) */
-    static int lowp = -1;
-    if (lowp < 0) {
-        const char *env = getenv("VIT_HIP_ATTN_LOWP");
-        lowp = (env && env[0] == '0') ? 0 : 1;
-    }
-    return launch_attention(s, qkv, output, 1, lowp ? 1 : 3, n_images, tokens, embed_dim, num_heads);
-}
-
 /* The fp32 attention writing its output as the three-part split planes [E/32][3][n_images*tokens][32] that
  * vh_launch_linear_p3 reads (same values as vh_launch_attention, split exactly). */
 extern "C" int vh_launch_attention_p3(vh_stream_t s, const float *qkv, void *out_planes, int n_images,
@@ -515,18 +494,14 @@ extern "C" int vh_launch_attention_p3(vh_stream_t s, const float *qkv, void *out
 }
 
 /* The bf16-operand mode's attention writing one-part planes [E/32][1][n_images*tokens][32] (bf16) for
- * vh_launch_linear_planes(parts = 1); same arithmetic as vh_launch_attention_bf16. */
+ * vh_launch_linear_planes(parts = 1): the arithmetic of vh_launch_attention_f16 (Q, K, V, P rounded to fp16 for the
+ * two products, fp32 softmax), the result rounded to bf16. */
 extern "C" int vh_launch_attention_planes_bf16(vh_stream_t s, const float *qkv, void *out_planes, int n_images,
                                                int tokens, int embed_dim, int num_heads)
 {
     if (embed_dim != num_heads * HD || tokens > MAX_ROWS)
         return vh_fail(1, "vh_launch_attention_planes_bf16: needs head_dim 64 and tokens <= %d", MAX_ROWS);
-    static int lowp = -1;
-    if (lowp < 0) {
-        const char *env = getenv("VIT_HIP_ATTN_LOWP");
-        lowp = (env && env[0] == '0') ? 0 : 1;
-    }
-    return launch_attention(s, qkv, out_planes, 4, lowp ? 1 : 3, n_images, tokens, embed_dim, num_heads);
+    return launch_attention(s, qkv, out_planes, 4, 1, n_images, tokens, embed_dim, num_heads);
 }
 
 /* The emulation mode's attention: Q.K^T and P.V on two fp16 parts / three products (kernelHandler.h,

@@ -8,15 +8,16 @@
  * (layer_norm.cl:55-65) and -- through the im2row A-loader and the token
  * epilogue -- `conv2d_kernel` + `postprocess` (conv2d.cl:1-80).
  *
- * Arithmetic (operands -> matrix instruction), all with fp32 accumulation:
- *   fp32, default   exact 3-way bf16 split of both operands, six v_mfma_f32_16x16x32_bf16 per
- *                   product block (SPLIT3 below): fp32-level results at 2.67x the fp32 MFMA peak
- *   fp32, native    v_mfma_f32_32x32x2_f32 (VIT_HIP_GEMM_FP32=native; also the ragged-N classifier)
- *   bf16            v_mfma_f32_16x16x32_bf16           (BASELINE config 3, opt-in)
+ * This file: the GEMMs whose fp32 operands are split INSIDE the K loop, and the alternates.  The model's four
+ * big projections run in gemm_p3.hip (both operands pre-split by their producers); here are
+ *   fp32, default   exact 3-way bf16 split of both operands in registers, six v_mfma_f32_16x16x32_bf16 per
+ *                   product block: vh_launch_linear on raw fp32 weights and the patch embedding (im2row on load);
+ *                   with the weights pre-split into planes (vh_launch_linear_w3) only the activations are split
+ *   fp32, native    v_mfma_f32_32x32x2_f32: the ragged-N classifier, and everything under VIT_HIP_GEMM_FP32=native
+ *   fp16 pairs      vh_launch_linear_h2 (opt-in emulation mode: two fp16 parts, three products)
  *   fp8 (e4m3)      v_mfma_f32_16x16x32_fp8_fp8 + per-column rescale (BASELINE config 5, opt-in)
  * Two kernel templates share one staging scheme: gemm_mf16_kernel (the 16x16x32 shapes) and
- * gemm_f32_kernel (native fp32, ragged N, and the 32x32x16 form of SPLIT3 behind
- * VIT_HIP_GEMM_MFMA=32 -- under load the chip holds a higher clock on 16x16x32).
+ * gemm_f32_kernel (native fp32, ragged N).
  *
  * Staging (MI355X / CDNA4):
  *  - Block tiles of BM x BN (template: 128x128 ... 256x256) x one 128-byte K step, cut into
@@ -55,11 +56,9 @@ constexpr int BK = 32;   /* 32-bit words per LDS row: 32 fp32 or 64 bf16 K eleme
 
 enum { A_ROWS = 0, A_PATCH = 1 };
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
-enum { K_F32 = 0, K_BF16 = 1, K_FP8 = 2 };
-#ifndef SGB_M
-#define SGB_M 1   /* scheduled SPLIT3 loop: SGB_M MFMAs, then SGB_V VALU instructions, repeated */
+enum { K_F32 = 0, K_FP8 = 2 };   /* element kind of GEMM operands / output */
+#define SGB_M 1   /* scheduled split loop: SGB_M MFMAs, then SGB_V VALU instructions, repeated (measured best of 1:1 .. 3:6) */
 #define SGB_V 2
-#endif   /* element kind of GEMM operands / output */
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -100,29 +99,14 @@ struct GemmParams {
     int img, patch, chans, grid, tokens;
 };
 
-/* BF16IN: A and W are bf16 (one ds_read_b128 = 8 K elements = one v_mfma_f32_32x32x16_bf16
- * operand, natural k order); otherwise fp32 (four v_mfma_f32_32x32x2_f32 per read).
- * BF16OUT: the result is rounded to bf16 (it feeds the next bf16 GEMM and nothing else). */
-/* SPLIT3 (fp32 operands only): fp32-equivalent products on the bf16 matrix cores.
- * Each fp32 operand x is split exactly into three bf16 parts, x = x0 + x1 + x2
- * (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); 3 x 8 significant bits cover
- * the 24-bit significand), in registers, after the fragment has been read from LDS.
- * a*b is then the sum of the six partial products of weight >= 2^-16,
- *     a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1,
- * each exact in fp32 (8 x 8 bits) and accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
- * The three dropped products are <= 2^-24 |ab| each: measured, the truncation error of a
- * K = 768 dot product is 6e-9 of its magnitude, against 1e-6 for the reference's own
- * sequential fp32 accumulation (tools/split3_numerics.py).  Six bf16 MFMAs (6 x 32 cycles
- * for a 32x32x16 block) replace eight fp32 MFMAs (8 x 64 cycles): 2.67x the fp32 MFMA
- * peak, paid for with ~44 VALU instructions per 8-element fragment. */
-template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false, bool SPLIT3 = false>
+/* The native fp32 matrix instruction (v_mfma_f32_32x32x2_f32: exact fp32, 1/16 of the bf16 rate): the
+ * classifier head (ragged N), and every projection under VIT_HIP_GEMM_FP32=native. */
+template <class T, int AMODE, int EPI, bool NGUARD>
 __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(const GemmParams p)
 {
-    static_assert(!(SPLIT3 && BF16IN), "SPLIT3 splits fp32 operands");
     constexpr int BM = T::BM, BN = T::BN, IT = T::IT, JT = T::JT;
-    constexpr int ES = BF16IN ? 2 : 4;   /* operand element size */
+    constexpr int ES = 4;                /* operand element size */
     constexpr int KE = 128 / ES;         /* K elements per step (one 128-byte LDS row) */
-    static_assert(!(BF16IN && AMODE == A_PATCH), "im2row loader is fp32 only");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -221,46 +205,13 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
 #pragma unroll
         for (int j = 0; j < JT; ++j)
             b[j] = *reinterpret_cast<const f32x4 *>(w_base + j * 32 * BK + koff[kk]);
-        if (BF16IN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < IT; ++i)
 #pragma unroll
                 for (int j = 0; j < JT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < IT; ++i)
-#pragma unroll
-                    for (int j = 0; j < JT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    /* One 16-deep k group (two ds_read_b128 per fragment) on the bf16 cores. */
-    auto compute_k16 = [&](const float *a_base, const float *w_base, int s16) {
-        bf16x8 a0[IT], a1[IT], a2[IT], b0[JT], b1[JT], b2[JT];
-#pragma unroll
-        for (int i = 0; i < IT; ++i)
-            split8(*reinterpret_cast<const f32x4 *>(a_base + i * 32 * BK + koff[2 * s16]),
-                   *reinterpret_cast<const f32x4 *>(a_base + i * 32 * BK + koff[2 * s16 + 1]), a0[i], a1[i], a2[i]);
-#pragma unroll
-        for (int j = 0; j < JT; ++j)
-            split8(*reinterpret_cast<const f32x4 *>(w_base + j * 32 * BK + koff[2 * s16]),
-                   *reinterpret_cast<const f32x4 *>(w_base + j * 32 * BK + koff[2 * s16 + 1]), b0[j], b1[j], b2[j]);
-#pragma unroll
-        for (int i = 0; i < IT; ++i)
-#pragma unroll
-            for (int j = 0; j < JT; ++j) { /* smallest terms first */
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b0[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b2[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
-            }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     };
 
     const int nk = p.K / KE;
@@ -274,15 +225,9 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
         const float *As = smem + cur * T::STAGE_F, *Ws = As + BM * BK;
         const float *a_base = As + (wm * 32 * IT + lr) * BK;
         const float *w_base = Ws + (wn * 32 * JT + lr) * BK;
-        if (SPLIT3) {
 #pragma unroll
-            for (int s16 = 0; s16 < BK / 16; ++s16)
-                compute_k16(a_base, w_base, s16);
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk)
-                compute_kk(a_base, w_base, kk);
-        }
+        for (int kk = 0; kk < BK / 8; ++kk)
+            compute_kk(a_base, w_base, kk);
         __syncthreads();
     }
 
@@ -315,10 +260,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_f32_kernel(
                     v = p.R[orow * p.N + col] + v;
                 if (EPI == EPI_PATCH)
                     v = v + posrow[col];
-                if (BF16OUT)
-                    static_cast<__bf16 *>(p.C)[orow * p.N + col] = (__bf16)v;
-                else
-                    static_cast<float *>(p.C)[orow * p.N + col] = v;
+                static_cast<float *>(p.C)[orow * p.N + col] = v;
             }
         }
     }
@@ -416,8 +358,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     constexpr int BM = T::BM, BN = T::BN;
     constexpr int IT = BM / T::WM / 16, JT = BN / T::WN / 16;   /* 16x16 blocks per wave */
     constexpr int IC = IT < 4 ? IT : 4;                          /* A fragments split at a time */
-    constexpr bool BF16IN = INK == K_BF16, FP8IN = INK == K_FP8;
-    constexpr int ES = FP8IN ? 1 : BF16IN ? 2 : 4;
+    constexpr bool FP8IN = INK == K_FP8;
+    constexpr int ES = FP8IN ? 1 : 4;
     constexpr int KE = 128 / ES;
     static_assert(!(INK != K_F32 && AMODE == A_PATCH), "im2row loader is fp32 only");
     static_assert(IT % IC == 0, "row blocks per wave");
@@ -431,7 +373,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / T::WN, wn = wave % T::WN, l15 = lane & 15, q = lane >> 4;
 
-    static_assert(NPL == 0 || (SCHED && INK == K_F32), "pre-split weight planes go with the scheduled fp32 loop");
+    static_assert(NPL == 0 || (SCHED && INK == K_F32 && IT < JT), "pre-split weight planes: scheduled fp32 loop, wave tile wider along N");
     constexpr int STG = T::stage_f(NPL);   /* floats per LDS stage */
     Staging<T, AMODE, ES, NPL> stg;
     stg.init(p, m0, n0, wave, lane);
@@ -477,23 +419,6 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
 #pragma unroll
                         for (int j = 0; j < JT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w[j][m], a[m], acc[i][j], 0, 0, 0);
-                }
-            }
-        } else if constexpr (BF16IN) {
-            /* 64 bf16 per LDS row = two 32-deep groups; one ds_read_b128 per fragment */
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int ko = 4 * ((4 * g + q) ^ swz);
-                bf16x8 w[JT];
-#pragma unroll
-                for (int j = 0; j < JT; ++j)
-                    w[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + ko));
-#pragma unroll
-                for (int i = 0; i < IT; ++i) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(ab + i * 16 * BK + ko));
-#pragma unroll
-                    for (int j = 0; j < JT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a, acc[i][j], 0, 0, 0);
                 }
             }
         } else if constexpr (SCHED) {
@@ -552,33 +477,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
-            bf16x8 w0[JT], w1[JT], w2[JT];
-#pragma unroll
-            for (int j = 0; j < JT; ++j)
-                split8(*reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k0),
-                       *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + k1), w0[j], w1[j], w2[j]);
-#pragma unroll
-            for (int ih = 0; ih < IT; ih += IC) {
-                bf16x8 a0[IC], a1[IC], a2[IC];
-#pragma unroll
-                for (int ii = 0; ii < IC; ++ii)
-                    split8(*reinterpret_cast<const f32x4 *>(ab + (ih + ii) * 16 * BK + k0),
-                           *reinterpret_cast<const f32x4 *>(ab + (ih + ii) * 16 * BK + k1), a0[ii], a1[ii], a2[ii]);
-#pragma unroll
-                for (int ii = 0; ii < IC; ++ii)
-#pragma unroll
-                    for (int j = 0; j < JT; ++j) { /* smallest terms first */
-                        f32x4 c = acc[ih + ii][j];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a2[ii], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j], a0[ii], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], a1[ii], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a1[ii], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], a0[ii], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a0[ii], c, 0, 0, 0);
-                        acc[ih + ii][j] = c;
-                    }
-            }
+            static_assert(FP8IN || SCHED, "fp32 operands use the scheduled loop");
         }
     };
 
@@ -698,104 +597,6 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             last_group_refill(NC - 1, nxt + wpo, 0, more);
             __builtin_amdgcn_sched_barrier(0);
         }
-    } else if constexpr (NPL != 0) {
-        /* K loop pipelined across steps.  With the weights pre-split a step's only VALU work is
-         * the A splits, so the barrier can sit before the LAST fragment group (by then every
-         * wave has read all of tile t): behind that group's MFMAs the W fragments of tile t+1
-         * are fetched in place (W[j] is dead once its MFMAs are issued) and A fragment 0 of
-         * tile t+1 is split -- the next step starts on its MFMAs at once. */
-        static_assert(IT >= 3, "pipeline depth");
-        typedef typename PartT<NPL>::type frag_t;
-        constexpr int NT6 = NPL == 3 ? 6 : 3;                 /* products per block */
-        constexpr int VPM = 2;                                /* split instructions per MFMA slot */
-        const int k0 = 4 * ((2 * q) ^ swz), k1 = 4 * ((2 * q + 1) ^ swz);
-        const int wpo = BM * BK + (wn * 16 * JT + l15) * 16 + 4 * (q ^ ((l15 >> 2) & 3));
-        frag_t w[JT][NPL], c[NPL];
-        f32x4 ra[2][2];
-        auto read_w = [&](const float *base, int j) {
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-                w[j][pl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const f32x4 *>(base + pl * BN * 16 + j * 256));
-        };
-        auto read_a01 = [&](const float *ab) {
-            ra[0][0] = *reinterpret_cast<const f32x4 *>(ab + k0);
-            ra[0][1] = *reinterpret_cast<const f32x4 *>(ab + k1);
-            ra[1][0] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k0);
-            ra[1][1] = *reinterpret_cast<const f32x4 *>(ab + 16 * BK + k1);
-        };
-        auto mfma_group = [&](int i) { /* per accumulator: smallest terms first */
-#pragma unroll
-            for (int t = 0; t < NT6; ++t)
-#pragma unroll
-                for (int j = 0; j < JT; ++j)
-                    acc[i][j] = mfma_part(w[j][term_w<NPL>(t)], c[term_a<NPL>(t)], acc[i][j]);
-        };
-        auto interleave = [&]() {
-#pragma unroll
-            for (int r = 0; r < NT6 * JT - 2; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        };
-        /* groups first .. IT-2: read fragment i+2, split fragment i+1, MFMAs of fragment i */
-        auto front = [&](const float *ab) {
-#pragma unroll
-            for (int i = 0; i < IT - 1; ++i) {
-                frag_t n[NPL];
-                split_parts(ra[(i + 1) & 1][0], ra[(i + 1) & 1][1], n);
-                if (i + 2 < IT) {
-                    ra[i & 1][0] = *reinterpret_cast<const f32x4 *>(ab + (i + 2) * 16 * BK + k0);
-                    ra[i & 1][1] = *reinterpret_cast<const f32x4 *>(ab + (i + 2) * 16 * BK + k1);
-                }
-                mfma_group(i);
-                if (i + 2 < IT)
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                interleave();
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                    c[pl] = n[pl];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-
-        stg.dma(p, smem, 0, 0, wave);
-        __syncthreads();
-        if (nk > 1)
-            stg.dma(p, smem, 1, 1, wave);
-#pragma unroll
-        for (int j = 0; j < JT; ++j)
-            read_w(smem + wpo, j);
-        read_a01(a_lane);
-        split_parts(ra[0][0], ra[0][1], c);
-        __builtin_amdgcn_sched_barrier(0);
-
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            front(a_lane + (kt & 1) * STG);
-            __syncthreads();                  /* tile kt read by every wave; tile kt+1 has landed */
-            if (kt + 2 < nk)
-                stg.dma(p, smem, kt & 1, kt + 2, wave);
-            const float *nx = smem + ((kt + 1) & 1) * STG;
-            frag_t n[NPL];
-            read_a01(nx + (wm * 16 * IT + l15) * BK);
-#pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                f32x4 cc = acc[IT - 1][j];
-#pragma unroll
-                for (int t = 0; t < NT6; ++t)
-                    cc = mfma_part(w[j][term_w<NPL>(t)], c[term_a<NPL>(t)], cc);
-                acc[IT - 1][j] = cc;
-                read_w(nx + wpo, j);          /* in place: W(kt)[j] is dead from here on */
-            }
-            split_parts(ra[0][0], ra[0][1], n);
-            interleave();
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-                c[pl] = n[pl];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        front(a_lane + ((nk - 1) & 1) * STG);
-        mfma_group(IT - 1);
     } else {
         stg.dma(p, smem, 0, 0, wave);
         __syncthreads();
@@ -840,10 +641,6 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             if (OUTK == K_FP8) {
                 *reinterpret_cast<unsigned *>(static_cast<unsigned char *>(p.C) + orow * p.N + col) =
                     pack_fp8x4(v * p.out_scale);
-            } else if (OUTK == K_BF16) {
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(p.C) + orow * p.N + col) = o;
             } else {
                 *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + orow * p.N + col) = v;
             }
@@ -874,40 +671,25 @@ __global__ void cls_rows_kernel(const float *cls, const float *pos, float *token
     tokens[(size_t)b * tokens_per_image * E + e] = cls[e] + pos[e];
 }
 
-template <class T, int AMODE, int EPI, bool NGUARD, bool BF16IN = false, bool BF16OUT = false, bool SPLIT3 = false>
+template <class T, int AMODE, int EPI, bool NGUARD>
 int launch_tile(hipStream_t st, GemmParams p)
 {
-    VH_SET_LDS_ONCE((gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT, SPLIT3>), T::LDS);
+    VH_SET_LDS_ONCE((gemm_f32_kernel<T, AMODE, EPI, NGUARD>), T::LDS);
     p.mtiles = (p.M + T::BM - 1) / T::BM;
     p.ntiles = (p.N + T::BN - 1) / T::BN;
-    hipLaunchKernelGGL((gemm_f32_kernel<T, AMODE, EPI, NGUARD, BF16IN, BF16OUT, SPLIT3>),
+    hipLaunchKernelGGL((gemm_f32_kernel<T, AMODE, EPI, NGUARD>),
                        dim3(p.mtiles * p.ntiles), dim3(T::NT), T::LDS, st, p);
     VH_LAUNCH_CHECK("gemm_f32_kernel");
     return 0;
 }
 
-/* Tile configurations.  VIT_HIP_GEMM_CFG=<id> overrides the per-shape choice (tuning
- * knob; every configuration computes the same k order, so results are identical). */
-using Tile0 = Tile<128, 128, 2, 4>; /*  8 waves of 64x32, 2 workgroups per CU */
+/* Tile configurations (every configuration computes the same k order, so results are identical). */
+using Tile0 = Tile<128, 128, 2, 4>; /*  8 waves of 64x32, 2 workgroups per CU: ragged N (native fp32), fp8 small */
 using Tile1 = Tile<128, 128, 2, 2>; /*  4 waves of 64x64, 2 workgroups per CU */
-using Tile2 = Tile<256, 128, 4, 2>; /*  8 waves of 64x64, 1 workgroup per CU  */
-using Tile3 = Tile<256, 256, 2, 4>; /*  8 waves of 128x64                      */
-using Tile4 = Tile<256, 256, 4, 4>; /* 16 waves of 64x64                       */
-using Tile5 = Tile<256, 128, 4, 4>; /* 16 waves of 64x32                       */
-using Tile6 = Tile<128, 256, 2, 4>; /*  8 waves of 64x64                       */
-using Tile7 = Tile<256, 256, 2, 2>; /*  4 waves of 128x128, one per SIMD       */
+using Tile3 = Tile<256, 256, 2, 4>; /*  8 waves of 128x64 */
+using Tile4 = Tile<256, 256, 4, 4>; /* 16 waves of 64x64: native fp32, fp8 */
 using Tile8 = Tile<256, 256, 4, 2>; /*  8 waves of 64x128 (pre-split weights: fewer A splits per wave) */
 using Tile9 = Tile<128, 128, 4, 1>; /*  4 waves of 32x128, 2 workgroups per CU */
-
-int cfg_override()
-{
-    static int v = -2;
-    if (v == -2) {
-        const char *env = getenv("VIT_HIP_GEMM_CFG");
-        v = (env && env[0] >= '0' && env[0] <= '9') ? env[0] - '0' : -1;
-    }
-    return v;
-}
 
 /* fp32 products: the exact 3-way bf16 split on the bf16 cores (default), or the native
  * fp32 MFMA (VIT_HIP_GEMM_FP32=native).  Both give fp32-level results (same measured
@@ -922,79 +704,23 @@ bool use_split3()
     return v == 1;
 }
 
-bool mfma_shape16()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *env = getenv("VIT_HIP_GEMM_MFMA");   /* "32": the 32x32x16 shape */
-        v = (env && env[0] == '3' && env[1] == '2') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-bool sched_variant()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *env = getenv("VIT_HIP_GEMM_SCHED");   /* "0": the compiler's own instruction order */
-        v = (env && env[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
 bool aligned16(const GemmParams &p)
 {
     return (((uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.R | (uintptr_t)p.pos) & 15) == 0;
 }
 
+/* fp32 operands, both split inside the K loop (vh_launch_linear on raw fp32 weights, and the patch
+ * embedding): 256x256 tiles where N allows and there is enough work, else 128x128. */
 template <int AMODE, int EPI>
-int launch(hipStream_t st, const GemmParams &p, int default_cfg)
+int launch(hipStream_t st, const GemmParams &p)
 {
+    const bool big = p.N % 256 == 0 && p.M >= 4096 && !(EPI == EPI_RESID && p.K < 2048);
     if (p.N % 128 != 0)                      /* ragged N: only the guarded 128x128 tile */
         return launch_tile<Tile0, AMODE, EPI, true>(st, p);
-    if (use_split3()) {
-        /* measured per shape (profiles/): 256x256 with 8 waves of 128x64 (fewest fragment
-         * splits per MFMA) wherever N allows and there is enough work; the N = 768, K = 768
-         * out-projection prefers 128x128 with two workgroups per CU */
-        int c = cfg_override();
-        if (c < 0)
-            c = (p.N % 256 == 0 && p.M >= 4096 && !(EPI == EPI_RESID && p.K < 2048)) ? 3 : 1;
-        if ((c == 3 || c == 4 || c == 7) && p.N % 256 != 0)
-            c = 1;
-        if (mfma_shape16() && aligned16(p) && sched_variant()) {
-            switch (c) {
-            case 1: return launch_mf16<Tile1, AMODE, EPI, K_F32, K_F32, true>(st, p);
-            case 7: return launch_mf16<Tile7, AMODE, EPI, K_F32, K_F32, true>(st, p);
-            default: return launch_mf16<Tile3, AMODE, EPI, K_F32, K_F32, true>(st, p);
-            }
-        }
-        if (mfma_shape16() && aligned16(p)) {
-            switch (c) {
-            case 1: return launch_mf16<Tile1, AMODE, EPI, K_F32, K_F32>(st, p);
-            case 7: return launch_mf16<Tile7, AMODE, EPI, K_F32, K_F32>(st, p);
-            default: return launch_mf16<Tile3, AMODE, EPI, K_F32, K_F32>(st, p);
-            }
-        }
-        switch (c) {
-        case 0: return launch_tile<Tile0, AMODE, EPI, false, false, false, true>(st, p);
-        case 1: return launch_tile<Tile1, AMODE, EPI, false, false, false, true>(st, p);
-        case 3: return launch_tile<Tile3, AMODE, EPI, false, false, false, true>(st, p);
-        case 7: return launch_tile<Tile7, AMODE, EPI, false, false, false, true>(st, p);
-        default: return launch_tile<Tile4, AMODE, EPI, false, false, false, true>(st, p);
-        }
-    }
-    int cfg = cfg_override() >= 0 && cfg_override() <= 6 ? cfg_override() : default_cfg;
-    if ((cfg == 3 || cfg == 4 || cfg == 6) && p.N % 256 != 0)
-        cfg = 2;
-    switch (cfg) {
-    case 1: return launch_tile<Tile1, AMODE, EPI, false>(st, p);
-    case 2: return launch_tile<Tile2, AMODE, EPI, false>(st, p);
-    case 3: return launch_tile<Tile3, AMODE, EPI, false>(st, p);
-    case 4: return launch_tile<Tile4, AMODE, EPI, false>(st, p);
-    case 5: return launch_tile<Tile5, AMODE, EPI, false>(st, p);
-    case 6: return launch_tile<Tile6, AMODE, EPI, false>(st, p);
-    default: return launch_tile<Tile0, AMODE, EPI, false>(st, p);
-    }
+    if (use_split3() && aligned16(p))
+        return big ? launch_mf16<Tile3, AMODE, EPI, K_F32, K_F32, true>(st, p)
+                   : launch_mf16<Tile1, AMODE, EPI, K_F32, K_F32, true>(st, p);
+    return big ? launch_tile<Tile4, AMODE, EPI, false>(st, p) : launch_tile<Tile0, AMODE, EPI, false>(st, p);
 }
 
 } // namespace
@@ -1016,63 +742,12 @@ extern "C" int vh_launch_linear(vh_stream_t s, float *output, const float *weigh
     p.A = input; p.W = weight; p.bias = bias; p.R = residual; p.C = output;
     p.M = rowA; p.N = colB; p.K = colA;
     hipStream_t st = (hipStream_t)s;
-    /* Tile choice per shape, measured on ViT-B/16 at M = 100 864 (profiles/): wide
-     * outputs amortise operand traffic best with 256x256 / 16 waves; the N = 768
-     * projections prefer 128x128 tiles (more workgroups per round, two per CU). */
-    const bool wide = colB % 256 == 0 && colB >= 1536 && rowA >= 4096;
     if (doGelu)
-        return launch<A_ROWS, EPI_GELU>(st, p, wide ? 4 : 0);
+        return launch<A_ROWS, EPI_GELU>(st, p);
     if (residual)
-        return launch<A_ROWS, EPI_RESID>(st, p, colA >= 2048 ? 1 : 0);
-    return launch<A_ROWS, EPI_NONE>(st, p, wide ? 4 : 0);
+        return launch<A_ROWS, EPI_RESID>(st, p);
+    return launch<A_ROWS, EPI_NONE>(st, p);
 }
-
-namespace {
-
-/* bf16 operands, fp32 accumulate.  Tile choice: these launches are bandwidth-bound
- * (the bf16 MFMA is 16x the fp32 one), so they use the 256x256 / 16-wave tile for the
- * highest operand reuse per byte when N allows, else 128x128 / 8 waves. */
-template <int EPI, bool BF16OUT>
-int launch_bf16(hipStream_t st, const GemmParams &p)
-{
-    int cfg = cfg_override();
-    if (cfg < 0)
-        cfg = (p.N % 256 == 0 && p.M >= 4096) ? 4 : 0;
-    if ((cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7) && p.N % 256 != 0)
-        cfg = 0;
-    if (mfma_shape16() && aligned16(p)) {
-        switch (cfg) {
-        case 0: return launch_mf16<Tile0, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
-        case 1: return launch_mf16<Tile1, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
-        case 3: return launch_mf16<Tile3, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
-        case 7: return launch_mf16<Tile7, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
-        default: return launch_mf16<Tile4, A_ROWS, EPI, K_BF16, BF16OUT ? K_BF16 : K_F32>(st, p);
-        }
-    }
-    switch (cfg) {
-    case 1: return launch_tile<Tile1, A_ROWS, EPI, false, true, BF16OUT>(st, p);
-    case 2: return launch_tile<Tile2, A_ROWS, EPI, false, true, BF16OUT>(st, p);
-    case 3: return launch_tile<Tile3, A_ROWS, EPI, false, true, BF16OUT>(st, p);
-    case 4: return launch_tile<Tile4, A_ROWS, EPI, false, true, BF16OUT>(st, p);
-    default: return launch_tile<Tile0, A_ROWS, EPI, false, true, BF16OUT>(st, p);
-    }
-}
-
-__global__ void convert_bf16_kernel(const float *__restrict__ in, __bf16 *__restrict__ out, size_t n)
-{
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i + 3 < n) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + i);
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *reinterpret_cast<bf16x4 *>(out + i) = o;
-    } else {
-        for (size_t k = i; k < n; ++k)
-            out[k] = (__bf16)in[k];
-    }
-}
-
-} // namespace
 
 namespace {
 
@@ -1081,17 +756,9 @@ namespace {
 template <int EPI, int OUTK>
 int launch_fp8(hipStream_t st, const GemmParams &p)
 {
-    int cfg = cfg_override();
-    if (cfg < 0)
-        cfg = (p.N % 256 == 0 && p.M >= 4096) ? 4 : 0;
-    if ((cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7) && p.N % 256 != 0)
-        cfg = 0;
-    switch (cfg) {
-    case 0: return launch_mf16<Tile0, A_ROWS, EPI, K_FP8, OUTK>(st, p);
-    case 1: return launch_mf16<Tile1, A_ROWS, EPI, K_FP8, OUTK>(st, p);
-    case 3: return launch_mf16<Tile3, A_ROWS, EPI, K_FP8, OUTK>(st, p);
-    default: return launch_mf16<Tile4, A_ROWS, EPI, K_FP8, OUTK>(st, p);
-    }
+    if (p.N % 256 == 0 && p.M >= 4096)
+        return launch_mf16<Tile4, A_ROWS, EPI, K_FP8, OUTK>(st, p);
+    return launch_mf16<Tile0, A_ROWS, EPI, K_FP8, OUTK>(st, p);
 }
 
 __global__ void convert_fp8_kernel(const float *__restrict__ in, unsigned char *__restrict__ out, size_t n, float mult)
@@ -1201,28 +868,14 @@ namespace {
 template <int EPI, int NPL>
 int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
 {
-    int c = cfg_override();
-    /* the 256x256 tile as 8 waves of 64x128 (Tile8: half the A splits per wave) or of 128x64 (Tile3);
-     * VIT_HIP_GEMM_CFG=3 selects the latter */
-    const bool wide_n = c != 3;   /* measured, same box: +4.8 % (exact split) and +7.5 % (fp16 pairs) over Tile3 */
-    if (c != 1 && c != 9)
-        c = (p.N % 256 == 0 && p.M >= 4096 && !prefer_small) ? 3 : 1;
-    const bool small_wide = cfg_override() != 1;   /* 128x128 as 4 waves of 32x128 (Tile9) unless VIT_HIP_GEMM_CFG=1: -6 % on the out-projection */
-    if (c != 3)
-        return small_wide ? launch_mf16<Tile9, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p)
-                          : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
-    static int tail = -1;
-    if (tail < 0) {
-        const char *env = getenv("VIT_HIP_GEMM_TAIL");
-        tail = (env && env[0] == '0') ? 0 : 1;
-    }
+    if (!(p.N % 256 == 0 && p.M >= 4096 && !prefer_small))
+        return launch_mf16<Tile9, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
     const int num_cus = vh_device_cus(vh_current_device());
     const int ntiles = p.N / 256, mtiles = (p.M + 255) / 256;
     const long tiles = (long)mtiles * ntiles, full = tiles / num_cus, rem = tiles % num_cus;
     const int rows_big = (int)(full * num_cus / ntiles) * 256;
-    if (!tail || full < 1 || rem == 0 || 4 * rem > 3 * num_cus || rows_big <= 0 || rows_big >= p.M)
-        return wide_n ? launch_mf16<Tile8, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p)
-                      : launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
+    if (full < 1 || rem == 0 || 4 * rem > 3 * num_cus || rows_big <= 0 || rows_big >= p.M)
+        return launch_mf16<Tile8, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, p);
     GemmParams big = p, rest = p;
     big.M = rows_big;
     rest.M = p.M - rows_big;
@@ -1230,12 +883,8 @@ int launch_planes(hipStream_t st, GemmParams p, bool prefer_small)
     rest.C = static_cast<float *>(p.C) + (size_t)rows_big * p.N;
     if (p.R)
         rest.R = p.R + (size_t)rows_big * p.N;
-    const int rc = wide_n ? launch_mf16<Tile8, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big)
-                          : launch_mf16<Tile3, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big);
-    if (rc)
-        return rc;
-    return small_wide ? launch_mf16<Tile9, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, rest)
-                      : launch_mf16<Tile1, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, rest);
+    const int rc = launch_mf16<Tile8, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, big);
+    return rc ? rc : launch_mf16<Tile9, A_ROWS, EPI, K_F32, K_F32, true, NPL>(st, rest);
 }
 
 } // namespace
@@ -1398,38 +1047,6 @@ extern "C" int vh_launch_linear_fp8(vh_stream_t s, void *output, int output_kind
     return output_kind == 2 ? launch_fp8<EPI_NONE, K_FP8>(st, p) : launch_fp8<EPI_NONE, K_F32>(st, p);
 }
 
-extern "C" int vh_launch_convert_bf16(vh_stream_t s, const float *input, void *output, size_t count)
-{
-    if (!input || !output || count == 0)
-        return vh_fail(1, "vh_launch_convert_bf16: bad argument");
-    const size_t threads = (count + 3) / 4;
-    hipLaunchKernelGGL(convert_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s,
-                       input, static_cast<__bf16 *>(output), count);
-    VH_LAUNCH_CHECK("convert_bf16_kernel");
-    return 0;
-}
-
-extern "C" int vh_launch_linear_bf16(vh_stream_t s, void *output, int output_bf16, const void *weight,
-                                     const void *input, const float *bias, int rowA, int colA, int colB,
-                                     int doGelu, const float *residual)
-{
-    if (!output || !weight || !input || !bias)
-        return vh_fail(1, "vh_launch_linear_bf16: null pointer argument");
-    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % 64 != 0 || colB % 128 != 0)
-        return vh_fail(1, "vh_launch_linear_bf16: needs colA %% 64 == 0 and colB %% 128 == 0 (%d,%d,%d)", rowA, colA, colB);
-    if ((doGelu && residual) || (residual && output_bf16))
-        return vh_fail(1, "vh_launch_linear_bf16: unsupported epilogue combination");
-    GemmParams p = {};
-    p.A = input; p.W = weight; p.bias = bias; p.R = residual; p.C = output;
-    p.M = rowA; p.N = colB; p.K = colA;
-    hipStream_t st = (hipStream_t)s;
-    if (doGelu)
-        return output_bf16 ? launch_bf16<EPI_GELU, true>(st, p) : launch_bf16<EPI_GELU, false>(st, p);
-    if (residual)
-        return launch_bf16<EPI_RESID, false>(st, p);
-    return output_bf16 ? launch_bf16<EPI_NONE, true>(st, p) : launch_bf16<EPI_NONE, false>(st, p);
-}
-
 namespace {
 
 /* Patch geometries the im2row-on-load GEMM cannot take (patch % 4 != 0 or C*P*P % 32 != 0;
@@ -1507,9 +1124,8 @@ extern "C" int vh_launch_patch_embed_ws(vh_stream_t s, const float *images, cons
     hipLaunchKernelGGL(cls_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, st, cls_token,
                        pos_embed, tokens, n_images, p.tokens, embed_dim);
     VH_LAUNCH_CHECK("cls_rows_kernel");
-    const int cfg = (embed_dim % 256 == 0 && p.M >= 4096) ? 4 : 0;
     if (direct)
-        return launch<A_PATCH, EPI_PATCH>(st, p, cfg);
+        return launch<A_PATCH, EPI_PATCH>(st, p);
 
     const int Kp = (K + BK - 1) / BK * BK;
     float *rows = static_cast<float *>(workspace), *wpad = rows + (size_t)p.M * Kp;
@@ -1521,7 +1137,7 @@ extern "C" int vh_launch_patch_embed_ws(vh_stream_t s, const float *images, cons
                        embed_dim, K, Kp);
     VH_LAUNCH_CHECK("pad_rows_kernel");
     p.A = rows; p.W = wpad; p.K = Kp;
-    return launch<A_ROWS, EPI_PATCH>(st, p, cfg);
+    return launch<A_ROWS, EPI_PATCH>(st, p);
 }
 
 extern "C" int vh_launch_patch_embed(vh_stream_t s, const float *images, const float *conv_w,

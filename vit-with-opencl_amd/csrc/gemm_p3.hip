@@ -429,12 +429,7 @@ extern "C" int vh_launch_linear_planes(vh_stream_t s, void *output, int output_p
     p.row_begin = 0; p.row_end = rowA; p.a_rows = rowA;
     p.N = colB; p.K = colA;
     hipStream_t st = (hipStream_t)s;
-    static int force_small = -1;
-    if (force_small < 0) {
-        const char *env = getenv("VIT_HIP_P3_TILE");   /* "128": only the 128x128 tile (measurements) */
-        force_small = (env && env[0] == '1') ? 1 : 0;
-    }
-    const int small_only = force_small || (residual && colA < 2048);   /* the N = K = E output projection: measured */
+    const int small_only = residual && colA < 2048;   /* the N = K = E output projection: measured */
 #define VH_P3_DISPATCH(NPL)                                                                                          \
     do {                                                                                                             \
         if (doGelu)                                                                                                  \

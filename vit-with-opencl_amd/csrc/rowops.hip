@@ -36,7 +36,7 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 /* NV = 16-byte chunks per lane; handles embed_dim <= 256*NV, embed_dim % 4 == 0. */
-template <int NV, int OUTK> /* OUTK: 0 fp32, 1 bf16, 2 fp8 (scaled by out_mult) */
+template <int NV, int OUTK> /* OUTK: 0 fp32, 2 fp8 (scaled by out_mult) */
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta,
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
     f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(out) + (size_t)row * out_stride);
-    bf16x4 *dst16 = reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(out) + (size_t)row * out_stride);
     unsigned *dst8 = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(out) + (size_t)row * out_stride);
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
@@ -86,9 +85,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                 y[e] = (x[c][e] - mean) * inv_std * g[e] + bb[e];
             if (OUTK == 2) { /* the only consumer is an fp8-operand GEMM: scale and round once, here */
                 dst8[idx] = pack_fp8x4(y * out_mult);
-            } else if (OUTK == 1) { /* the only consumer is a bf16-operand GEMM: round once, here */
-                bf16x4 y16 = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
-                dst16[idx] = y16;
             } else {
                 dst[idx] = y;
             }
@@ -234,8 +230,6 @@ static int launch_layer_norm(vh_stream_t s, const float *input, const float *wei
     do {                                                                                            \
         if (out_kind == 2)                                                                          \
             VH_LN_K(NV, 2);                                                                         \
-        else if (out_kind == 1)                                                                     \
-            VH_LN_K(NV, 1);                                                                         \
         else                                                                                        \
             VH_LN_K(NV, 0);                                                                         \
     } while (0)
@@ -254,14 +248,6 @@ extern "C" int vh_launch_layer_norm(vh_stream_t s, const float *input, const flo
                                     long in_row_stride, long out_row_stride, double eps)
 {
     return launch_layer_norm(s, input, weight, bias, output, 0, 1.0f, rows, embed_dim, in_row_stride,
-                             out_row_stride, eps);
-}
-
-extern "C" int vh_launch_layer_norm_bf16(vh_stream_t s, const float *input, const float *weight,
-                                         const float *bias, void *output, int rows, int embed_dim,
-                                         long in_row_stride, long out_row_stride, double eps)
-{
-    return launch_layer_norm(s, input, weight, bias, output, 1, 1.0f, rows, embed_dim, in_row_stride,
                              out_row_stride, eps);
 }
 

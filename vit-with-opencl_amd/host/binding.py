@@ -34,7 +34,6 @@ EXPORTS = [
     "ViT_opencl", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
     "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_profile_select", "vit_hip_create_ex", "vit_hip_precision",
-    "vh_launch_convert_bf16", "vh_launch_layer_norm_bf16", "vh_launch_linear_bf16", "vh_launch_attention_bf16",
     "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_launch_split3_planes", "vh_launch_linear_w3",
     "vh_launch_split2h_planes", "vh_launch_linear_h2", "vh_launch_attention_h2", "vh_launch_attention_f16",
     "vh_launch_convert_fp8", "vh_launch_quantize_rows_fp8", "vh_launch_absmax", "vh_launch_scale_vector",
@@ -175,10 +174,6 @@ def lib() -> C.CDLL:
     L.vit_hip_create.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i]
     L.vit_hip_create_ex.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i, i]
     L.vit_hip_precision.argtypes = [voidp]
-    L.vh_launch_convert_bf16.argtypes = [voidp, voidp, voidp, sz]
-    L.vh_launch_layer_norm_bf16.argtypes = [voidp] + [voidp] * 4 + [i, i, C.c_long, C.c_long, C.c_double]
-    L.vh_launch_linear_bf16.argtypes = [voidp, voidp, i, voidp, voidp, voidp, i, i, i, i, voidp]
-    L.vh_launch_attention_bf16.argtypes = [voidp, voidp, voidp, i, i, i, i]
     f = C.c_float
     L.vh_launch_convert_fp8.argtypes = [voidp, voidp, voidp, sz, f]
     L.vh_launch_quantize_rows_fp8.argtypes = [voidp, voidp, voidp, voidp, i, i]
