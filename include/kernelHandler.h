@@ -160,6 +160,11 @@ int vh_launch_layer_norm_p3(vh_stream_t s, const float *input, const float *weig
 /* vh_launch_attention writing planes [embed_dim/32][3][n_images*tokens][32] (head_dim 64, tokens <= 208) */
 int vh_launch_attention_p3(vh_stream_t s, const float *qkv, void *out_planes, int n_images, int tokens,
                            int embed_dim, int num_heads);
+/* The same attention on PRE-SPLIT Q, K, V: qkv_planes [3*embed_dim/32][3][n_images*tokens][32] (the QKV projection
+ * written by vh_launch_linear_p3 with output_planes), out_planes as above; same results bit for bit, no split
+ * arithmetic left but that of the probabilities (csrc/attention_p3.hip).  head_dim 64, tokens <= 208. */
+int vh_launch_attention_planes(vh_stream_t s, const void *qkv_planes, void *out_planes, int n_images, int tokens,
+                               int embed_dim, int num_heads);
 /* vh_launch_linear on planes: input_planes [colA/32][3][rowA][32], weight_planes [colA/32][3][colB][32];
  * output fp32 [rowA][colB], or (output_planes != 0, no residual) planes [colB/32][3][rowA][32].
  * colA % 64 == 0, colB % 128 == 0. */

@@ -177,6 +177,27 @@ def test_attention_p3_equals_attention_split(pkg, device, oracle, n_images, toke
     assert np.array_equal(d_m.to_numpy((rows, E)), d_o.to_numpy((rows, E)) + 0.0)
 
 
+@pytest.mark.parametrize("n_images,tokens", [(1, 197), (3, 197), (2, 5), (1, 208), (40, 33), (300, 64), (2, 1)])
+def test_attention_on_planes_equals_attention_on_rows_bitwise(pkg, device, oracle, n_images, tokens):
+    """vh_launch_attention_planes (Q, K, V pre-split by the QKV projection's epilogue; csrc/attention_p3.hip)
+    against vh_launch_attention on the same fp32 rows: the same six products per block on the same k
+    assignment, the same softmax -- identical bits; and against the CPU oracle (ViT_seq.c:192-262)."""
+    E, H = 768, 12
+    rows = n_images * tokens
+    qkv = oracle.synth_fill(rows * 3 * E, 91 + tokens, 1.0, 0.0).reshape(rows, 3 * E)
+    d_q, d_q3 = _dev(pkg, qkv), _planes_buf(pkg, rows, 3 * E)
+    _launch(pkg, "vh_launch_split3_rows", None, d_q.ptr, d_q3.ptr, rows, 3 * E)
+    d_o, d_p, d_m = pkg.DeviceBuffer(rows * E), _planes_buf(pkg, rows, E), pkg.DeviceBuffer(rows * E)
+    _launch(pkg, "vh_launch_attention", None, d_q.ptr, d_o.ptr, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_attention_planes", None, d_q3.ptr, d_p.ptr, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_merge3_rows", None, d_p.ptr, d_m.ptr, rows, E)
+    got = d_m.to_numpy((rows, E))
+    assert np.array_equal(got, d_o.to_numpy((rows, E)) + 0.0)
+    if rows <= 600:
+        want = np.concatenate([oracle.attention(qkv[i * tokens:(i + 1) * tokens]) for i in range(n_images)])
+        assert np.abs(got - want).max() <= OP_TOL
+
+
 def test_p3_launchers_reject_bad_arguments(pkg, device):
     L = pkg.lib()
     d = pkg.DeviceBuffer(65536)

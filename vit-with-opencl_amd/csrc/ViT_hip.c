@@ -405,7 +405,7 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
     TRY(vh_malloc((void **)&ctx->x, rows * E * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->y, rows * E * act));
     TRY(vh_malloc((void **)&ctx->attn, rows * E * act));
-    TRY(vh_malloc((void **)&ctx->qkv, rows * 3 * E * sizeof(float)));
+    TRY(vh_malloc((void **)&ctx->qkv, rows * 3 * E * act));
     {   /* patch geometries that need gathered rows (H/14) borrow the MLP hidden buffer, idle at that point */
         const size_t ws = vh_patch_embed_workspace(max_batch, cfg->in_chans, cfg->img_size, cfg->patch_size, cfg->embed_dim);
         const size_t hid_bytes = rows * F * act;
@@ -506,12 +506,15 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         float **lw = w + 4 + 12 * l;
         void **l3 = ctx->w3 + 4 + 12 * l;
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, c->eps));
-        OP(VIT_OP_QKV, vh_launch_linear_p3(s, ctx->qkv, 0, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
-        if (E == 64 * c->num_heads && T <= 208)
-            OP(VIT_OP_ATTENTION, vh_launch_attention_p3(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-        else   /* shapes of the streaming attention kernel: fp32 output (into the idle MLP buffer), then split */
+        if (E == 64 * c->num_heads && T <= 208) {
+            /* Q, K, V too travel as planes: only the probabilities are split inside the attention kernel */
+            OP(VIT_OP_QKV, vh_launch_linear_p3(s, ctx->qkv, 1, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+            OP(VIT_OP_ATTENTION, vh_launch_attention_planes(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+        } else {   /* shapes of the streaming attention kernel: fp32 rows in, fp32 out (into the idle MLP buffer), then split */
+            OP(VIT_OP_QKV, vh_launch_linear_p3(s, ctx->qkv, 0, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
             OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
                                  vh_launch_split3_rows(s, ctx->hid, ctx->attn, rows, E));
+        }
         OP(VIT_OP_OUT_PROJ, vh_launch_linear_p3(s, ctx->x, 0, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, c->eps));
         OP(VIT_OP_FC1, vh_launch_linear_p3(s, ctx->hid, 1, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL));

@@ -7,6 +7,11 @@
 
 #include "vit_kernels.h"
 
+/* 16-byte chunk swizzle of a 64-byte LDS row r (plane rows: 32 bf16): chunk c sits at c ^ f((r >> 2) & 3),
+ * f = {0, 2, 3, 1} -- the 16 lanes of every ds_read_b128 group of a 16- or 32-row fragment then hit 16
+ * distinct slots of the 256-byte bank row.  Argument: r >> 2. */
+__device__ __forceinline__ int swz64(int r4) { return (0x78 >> (2 * (r4 & 3))) & 3; }
+
 /* Bijective XCD remap (blocks b and b+8 share an XCD; which one is not known
  * and not needed): XCD x gets a contiguous run of tiles. */
 __device__ __forceinline__ int xcd_tile(int bid, int nwg)

@@ -69,9 +69,6 @@ struct P3Params {
     int mtiles, ntiles;
 };
 
-/* 16-byte chunk swizzle of a 64-byte LDS row r: f((r >> 2) & 3), f = {0, 2, 3, 1} */
-__device__ __forceinline__ int swz64(int r4) { return (0x78 >> (2 * (r4 & 3))) & 3; }
-
 /* NPL = parts per value: 3 = the exact fp32 split (six products per block, the default fp32 path);
  * 1 = operands rounded to bf16 by their producers (one product per block: BASELINE config 3's
  * bf16-operand mode).  With one part a W fragment feeds 2 MFMAs instead of 12, so a stage holds two

@@ -40,7 +40,7 @@ EXPORTS = [
     "vh_launch_layer_norm_fp8", "vh_launch_linear_fp8", "vit_hip_calibrate_fp8", "vit_hip_fp8_scales",
     "vh_launch_split3_rows", "vh_launch_merge3_rows", "vh_launch_layer_norm_p3", "vh_launch_attention_p3",
     "vh_launch_linear_p3", "vh_launch_split_rows", "vh_launch_merge_rows", "vh_launch_layer_norm_planes",
-    "vh_launch_attention_planes_bf16", "vh_launch_linear_planes",
+    "vh_launch_attention_planes_bf16", "vh_launch_linear_planes", "vh_launch_attention_planes",
     "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
     "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
@@ -163,6 +163,7 @@ def lib() -> C.CDLL:
     L.vh_launch_merge_rows.argtypes = [voidp, voidp, voidp, i, i, i]
     L.vh_launch_layer_norm_planes.argtypes = [voidp] + [voidp] * 4 + [i, i, i, C.c_long, C.c_double]
     L.vh_launch_attention_planes_bf16.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_attention_planes.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_linear_planes.argtypes = [voidp, voidp, i, voidp, voidp, i, voidp, i, i, i, i, voidp]
     L.vit_config_preset.argtypes = [C.POINTER(VitConfig), C.c_char_p]
     L.vit_config_tokens.argtypes = [C.POINTER(VitConfig)]
