@@ -84,22 +84,18 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
                       int n_tensors, int device, int max_batch, int precision);
 int vit_hip_precision(const vit_hip_ctx *ctx);
 
-/* FP8_GEMM (BASELINE config 5: "fp8 weights (CDNA4 fp8 MFMA)"): the same four matrices as OCP
- * e4m3 bytes with one scale per output row, their inputs (LayerNorm outputs, attention
- * output, MLP hidden layer) as e4m3 with one calibrated scale per tensor, products on
- * v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation; everything else as in BF16_GEMM.
- * A context created with this precision must be calibrated once on representative images
- * before the first forward (which fails otherwise): the fp32 path runs over them and
- * records max |x| of every GEMM input.  Logits differ from ViT_seq.c at the 1e-1 level
- * (3-bit significands; tools/quant_report.py prints the per-layer error), so: opt-in only. */
-int vit_hip_calibrate_fp8(vit_hip_ctx *ctx, const float *d_images, int n);
+/* FP8_GEMM (BASELINE config 5: "fp8 weights (CDNA4 fp8 MFMA)"): the same four matrices and their inputs as block-scaled
+ * fp8 -- OCP "MX": e4m3 elements, one power-of-two scale per 32 consecutive K elements, computed where the tensor
+ * is produced (weights at context creation; LayerNorm, the fc1 epilogue and the attention output at run time), so
+ * there is NO calibration pass -- on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 rate; csrc/gemm_mx.hip).
+ * Everything else as in BF16_GEMM.  Opt-in ($VIT_HIP_PRECISION=fp8): logits differ from ViT_seq.c at the 1e-1 level
+ * (3-bit significands; tests state the tolerance). */
 
 /* F32_FP16X2: everything as in F32 except that the four big projections emulate the fp32 product
  * with two fp16 parts per operand and three matrix-core products (vh_launch_linear_h2) instead of
  * the exact three-part / six-product split.  Operands keep 22 of 24 significant bits; measured
  * class logits stay within the fp32 path's own tolerance of ViT_seq.c (1e-4; tests/test_gpu_parity.py),
  * but it is not an exact fp32 product, so: opt-in, never what `ViT_opencl` uses. */
-int vit_hip_fp8_scales(const vit_hip_ctx *ctx, float *out, int capacity);
 
 /* Host-pointer forward: gathers the n separately allocated images into pinned
  * staging, runs them in chunks of <= max_batch, and returns when all outputs

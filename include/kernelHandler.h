@@ -207,24 +207,26 @@ int vh_launch_softmax(vh_stream_t s, const float *input, float *output, int rows
 int vh_launch_attention_f16(vh_stream_t s, const float *qkv, float *output, int n_images,
                             int tokens, int embed_dim, int num_heads);
 
-/* ---- fp8 (OCP e4m3) operand variants (BASELINE config 5) ----
- * No reference counterpart.  Values are stored as x / scale rounded to e4m3 (saturating at
- * +-448); a GEMM rescales its raw sum by col_scale[n] = input_scale * weight_row_scale[n]
- * before adding the bias.  `*_multiplier` arguments are 1 / scale of the tensor written. */
-int vh_launch_convert_fp8(vh_stream_t s, const float *input, void *output, size_t count, float multiplier);
-int vh_launch_quantize_rows_fp8(vh_stream_t s, const float *weight, void *weight_fp8, float *row_scale,
-                                int rows, int cols);                /* row_scale[r] = max|row| / 448 */
-int vh_launch_absmax(vh_stream_t s, const float *input, size_t count, float *amax); /* atomic max into *amax */
-int vh_launch_scale_vector(vh_stream_t s, float *output, const float *input, float multiplier, int count);
-int vh_launch_layer_norm_fp8(vh_stream_t s, const float *input, const float *weight, const float *bias,
-                             void *output, float out_multiplier, int rows, int embed_dim,
-                             long in_row_stride, long out_row_stride, double eps);
-/* output (fp32 when output_kind == 0, e4m3 scaled by out_multiplier when 2) =
- *   (input_fp8 . weight_fp8^T) * col_scale + bias [+GELU | +residual] */
-int vh_launch_linear_fp8(vh_stream_t s, void *output, int output_kind, const void *weight,
-                         const void *input, const float *bias, const float *col_scale,
-                         float out_multiplier, int rowA, int colA, int colB, int doGelu,
-                         const float *residual);
+int vh_launch_absmax(vh_stream_t s, const float *input, size_t count, float *amax); /* atomic max |x| into *amax (fp16-pair mode: weight ranges) */
+
+/* ---- block-scaled fp8 ("MX": OCP microscaling) operand variants -- BASELINE config 5 at the fp8 matrix rate ----
+ * No reference counterpart.  An MX tensor [rows][cols] (cols % 128 == 0) is e4m3 elements with one e8m0
+ * power-of-two scale per 32 consecutive elements of a row (scale = the smallest 2^E with max|block| / 2^E <= 448,
+ * elements = e4m3_nearest_even(x / scale)), stored as
+ *     values[cols/128][rows][128] bytes      scales[cols/128][4][rows] bytes
+ * where scales[k][g][r] is the scale of block 2 (g & 1) + (g >> 1) of row r's K step k: the order in which the four
+ * lane groups of v_mfma_scale_f32_16x16x128_f8f6f4 consume them (csrc/gemm_mx.hip; tests/mx_ref.py is the numpy
+ * statement both are checked against byte for byte).  Scales are per block and computed where the tensor is
+ * produced: no calibration pass. */
+int vh_launch_quantize_mx_rows(vh_stream_t s, const float *input, void *values, void *scales, int rows, int cols);
+/* vh_launch_layer_norm writing its result as an MX tensor (embed_dim % 128 == 0) */
+int vh_launch_layer_norm_mx(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                            void *out_values, void *out_scales, int rows, int embed_dim, long in_row_stride, double eps);
+/* output (fp32 [rowA][colB]; or MX values + output_scales when output_scales != NULL, no residual) =
+ *   input_mx . weight_mx^T + bias [+GELU | +residual]; fp32 accumulation.  colA % 256 == 0, colB % 128 == 0. */
+int vh_launch_linear_mx(vh_stream_t s, void *output, void *output_scales, const void *weight_values,
+                        const void *weight_scales, const void *input_values, const void *input_scales,
+                        const float *bias, int rowA, int colA, int colB, int doGelu, const float *residual);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ __global__ void fill_random(float *x, size_t n, unsigned seed, float scale)
 template <int NW, int BN, int EPI, int OUTK, int LAB, int NPL = 3>
 void launch_variant(hipStream_t st, P3Params p)
 {
-    constexpr int LDS = 2 * (NPL == 3 ? 1 : 2) * NPL * BN * 64;
+    constexpr int LDS = 2 * (NPL == 3 ? 1 : P1_KG) * NPL * BN * 64;
     static bool set = false;
     if (!set) { CK(hipFuncSetAttribute((const void *)gemm_p3_kernel<NW, BN, EPI, OUTK, NPL, LAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
     p.mtiles = (p.row_end - p.row_begin + 32 * NW - 1) / (32 * NW);

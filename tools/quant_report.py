@@ -13,6 +13,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import __graft_entry__ as graft  # noqa: E402
 import fp8_ref  # noqa: E402
+import mx_ref  # noqa: E402
 
 
 def bf16_round(a):
@@ -21,9 +22,15 @@ def bf16_round(a):
 
 
 def fp8_rows(w):
+    """e4m3 with one scale per row (round 1's format; kept for comparison)"""
     s = (np.abs(w).max(axis=1) / np.float32(448.0)).astype(np.float32)
     s[s == 0] = 1.0
     return fp8_ref.dequantize(fp8_ref.quantize(w * (np.float32(1.0) / s)[:, None])) * s[:, None]
+
+
+def fp8_mx(w):
+    """block-scaled e4m3 (MX): what the fp8 mode stores"""
+    return mx_ref.dequantize(*mx_ref.quantize(w))
 
 
 def snr_db(ref, q):
@@ -43,14 +50,11 @@ def main():
         out_f = weights[4 + k + 1].size
         w2 = w.reshape(out_f, -1)
         print(f"  {name:9s} [{out_f}][{w2.shape[1]}]  bf16 {snr_db(w2, bf16_round(w2)):6.1f}   "
-              f"e4m3 + per-row scale {snr_db(w2, fp8_rows(w2)):6.1f}")
+              f"e4m3 + per-row scale {snr_db(w2, fp8_rows(w2)):6.1f}   e4m3 + 32-element block scales (MX) {snr_db(w2, fp8_mx(w2)):6.1f}")
     imgs = pkg.synth_images(cfg, 0, n)
     out = {}
     for prec in ("f32", "bf16", "fp8"):
         m = pkg.ViTHip(cfg, weights, device=0, max_batch=min(n, 64), precision=prec)
-        if prec == "fp8":
-            sc = m.calibrate_fp8(pkg.synth_images(cfg, 10000, min(n, 32)))
-            print("## fp8 activation scales (amax/448) layer 0:", sc[0], " last layer:", sc[-1])
         out[prec], _ = m.forward(imgs)
         m.close()
     ref = out["f32"]

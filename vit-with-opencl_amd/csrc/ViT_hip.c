@@ -50,20 +50,14 @@ struct vit_hip_ctx
     int precision;      /* VIT_PRECISION_F32 or VIT_PRECISION_BF16_GEMM */
     void *w16_slab;     /* bf16 copies of the four big matrices of every layer */
     void **w16;         /* per tensor index (NULL where no bf16 copy exists) */
-    /* FP8_GEMM: e4m3 copies of the same four matrices with one scale per output row, the
-     * calibrated per-tensor scales of the four GEMM inputs of every layer, and their products */
     /* F32: the same four matrices pre-split into three bf16 planes each (vh_launch_linear_w3) */
     void *w3_slab;
     void **w3;          /* per tensor index (NULL: use the fp32 tensor) */
     float *w3_scale;    /* F32_FP16X2: per tensor index, the power of two its fp16 parts were scaled by */
     int use_p3;         /* F32: GEMM inputs travel as three-part bf16 planes (y, attn, hid hold 6 bytes per value) */
+    /* FP8_GEMM: block-scaled e4m3 copies of the same four matrices (values, then their e8m0 block scales) */
     void *w8_slab;
-    void **w8;          /* per tensor index */
-    float *wscale_slab; /* per tensor index: [out_features] row scales, then [out_features] a_scale*row scale */
-    float **wscale, **colscale;
-    float *d_amax;      /* [depth][4] max |x| seen by calibration: LN1 out, attention out, LN2 out, MLP hidden */
-    float *act_scale;   /* host copy: amax / 448 */
-    int calibrating, calibrated;
+    void **w8, **w8s;   /* per tensor index: values, scales */
 
     /* activation arena (rows = max_batch * tokens) */
     float *x;           /* residual stream      [rows][E]   */
@@ -166,14 +160,8 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
     free(ctx->w3_scale);
     if (ctx->w8_slab)
         vh_free(ctx->w8_slab);
-    if (ctx->wscale_slab)
-        vh_free(ctx->wscale_slab);
-    if (ctx->d_amax)
-        vh_free(ctx->d_amax);
     free(ctx->w8);
-    free(ctx->wscale);
-    free(ctx->colscale);
-    free(ctx->act_scale);
+    free(ctx->w8s);
     float *dev[] = {ctx->w_slab, ctx->x, ctx->y, ctx->attn, ctx->qkv, ctx->hid,
                     ctx->cls, ctx->d_logits, ctx->d_probs, ctx->d_images[0], ctx->d_images[1]};
     for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); ++i)
@@ -200,11 +188,11 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
 int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                    int n_tensors, int device, int max_batch)
 {
-    /* F32 unless asked otherwise: "bf16" -> BF16_GEMM, "fp16x2" -> F32_FP16X2 (FP8_GEMM needs a calibration
-     * pass and is only reachable through vit_hip_create_ex) */
+    /* F32 unless asked otherwise: "bf16" -> BF16_GEMM, "fp16x2" -> F32_FP16X2, "fp8" -> FP8_GEMM */
     const char *env = getenv("VIT_HIP_PRECISION");
     const int precision = (env && env[0] == 'b') ? VIT_PRECISION_BF16_GEMM
-                        : (env && strncmp(env, "fp16x2", 6) == 0) ? VIT_PRECISION_F32_FP16X2 : VIT_PRECISION_F32;
+                        : (env && strncmp(env, "fp16x2", 6) == 0) ? VIT_PRECISION_F32_FP16X2
+                        : (env && strncmp(env, "fp8", 3) == 0) ? VIT_PRECISION_FP8_GEMM : VIT_PRECISION_F32;
     return vit_hip_create_ex(out, cfg, networks, n_tensors, device, max_batch, precision);
 }
 
@@ -221,7 +209,7 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
         return 1;
     if (precision == VIT_PRECISION_F32_FP16X2 && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
         return 2;
-    if (precision == VIT_PRECISION_FP8_GEMM && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
+    if (precision == VIT_PRECISION_FP8_GEMM && (cfg->embed_dim % 256 != 0 || cfg->mlp_hidden % 256 != 0))
         return 2;
     if (precision == VIT_PRECISION_BF16_GEMM && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
         return 2;
@@ -253,18 +241,14 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
     ctx->w3 = (void **)calloc((size_t)n_tensors, sizeof(void *));
     ctx->w3_scale = (float *)calloc((size_t)n_tensors, sizeof(float));
     ctx->w8 = (void **)calloc((size_t)n_tensors, sizeof(void *));
-    ctx->wscale = (float **)calloc((size_t)n_tensors, sizeof(float *));
-    ctx->colscale = (float **)calloc((size_t)n_tensors, sizeof(float *));
-    ctx->act_scale = (float *)calloc((size_t)cfg->depth * 4, sizeof(float));
-    if (!ctx->w || !ctx->w16 || !ctx->w3 || !ctx->w3_scale || !ctx->w8 || !ctx->wscale || !ctx->colscale || !ctx->act_scale) {
+    ctx->w8s = (void **)calloc((size_t)n_tensors, sizeof(void *));
+    if (!ctx->w || !ctx->w16 || !ctx->w3 || !ctx->w3_scale || !ctx->w8 || !ctx->w8s) {
         free(ctx->w);
         free(ctx->w16);
         free(ctx->w3);
         free(ctx->w3_scale);
         free(ctx->w8);
-        free(ctx->wscale);
-        free(ctx->colscale);
-        free(ctx->act_scale);
+        free(ctx->w8s);
         free(ctx);
         return 4;
     }
@@ -363,30 +347,26 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
     }
 
     if (precision == VIT_PRECISION_FP8_GEMM) {
-        /* e4m3 copies of in_proj, out_proj, fc1, fc2 with one scale per output row (= weight row);
-         * the activation scales come from vit_hip_calibrate_fp8() */
+        /* block-scaled fp8 copies of in_proj, out_proj, fc1, fc2: values (1 byte per weight) then the e8m0 scales
+         * (1 byte per 32 weights), both 256-byte aligned in one slab */
         static const int big[4] = {2, 4, 8, 10};
-        size_t total8 = 0, total_s = 0;
+        size_t total8 = 0;
         for (int l = 0; l < cfg->depth; ++l)
             for (int k = 0; k < 4; ++k) {
-                const int idx = 4 + 12 * l + big[k];
-                total8 += align_up(networks[idx].size, 256);
-                total_s += align_up(2 * networks[idx + 1].size * sizeof(float), 256); /* bias length = out features */
+                const size_t cnt = networks[4 + 12 * l + big[k]].size;
+                total8 += align_up(cnt, 256) + align_up(cnt / 32, 256);
             }
         TRY(vh_malloc(&ctx->w8_slab, total8));
-        TRY(vh_malloc((void **)&ctx->wscale_slab, total_s));
-        TRY(vh_malloc((void **)&ctx->d_amax, (size_t)cfg->depth * 4 * sizeof(float)));
-        size_t off8 = 0, off_s = 0;
+        size_t off8 = 0;
         for (int l = 0; l < cfg->depth; ++l)
             for (int k = 0; k < 4; ++k) {
                 const int idx = 4 + 12 * l + big[k];
-                const int out_f = (int)networks[idx + 1].size, in_f = (int)(networks[idx].size / networks[idx + 1].size);
+                const size_t cnt = networks[idx].size;
+                const int out_f = (int)networks[idx + 1].size, in_f = (int)(cnt / networks[idx + 1].size);
                 ctx->w8[idx] = (char *)ctx->w8_slab + off8;
-                ctx->wscale[idx] = (float *)((char *)ctx->wscale_slab + off_s);
-                ctx->colscale[idx] = ctx->wscale[idx] + out_f;
-                TRY(vh_launch_quantize_rows_fp8(ctx->stream, ctx->w[idx], ctx->w8[idx], ctx->wscale[idx], out_f, in_f));
-                off8 += align_up(networks[idx].size, 256);
-                off_s += align_up(2 * (size_t)out_f * sizeof(float), 256);
+                ctx->w8s[idx] = (char *)ctx->w8_slab + off8 + align_up(cnt, 256);
+                TRY(vh_launch_quantize_mx_rows(ctx->stream, ctx->w[idx], ctx->w8[idx], ctx->w8s[idx], out_f, in_f));
+                off8 += align_up(cnt, 256) + align_up(cnt / 32, 256);
             }
     }
 
@@ -450,26 +430,23 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_ws(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n, c->in_chans,
                                                     c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
 
-    const int mode = ctx->calibrating ? VIT_PRECISION_F32 : ctx->precision;
-    if (mode == VIT_PRECISION_FP8_GEMM && !ctx->calibrated) {
-        fprintf(stderr, "vit_hip_forward: FP8_GEMM context is not calibrated (vit_hip_calibrate_fp8)\n");
-        return 5;
-    }
+    const int mode = ctx->precision;
     for (int l = 0; l < c->depth && mode == VIT_PRECISION_FP8_GEMM; ++l) {
-        /* fp8 GEMM operands: y and hid hold e4m3 bytes (same allocations, a quarter used); y also
-         * takes the quantised attention output once the QKV GEMM has consumed the LN output */
-        float **lw = w + 4 + 12 * l, **cs = ctx->colscale + 4 + 12 * l;
-        void **lw8 = ctx->w8 + 4 + 12 * l;
-        const float *as = ctx->act_scale + 4 * l;
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_fp8(s, ctx->x, lw[0], lw[1], ctx->y, 1.0f / as[0], rows, E, E, E, c->eps));
-        OP(VIT_OP_QKV, vh_launch_linear_fp8(s, ctx->qkv, 0, lw8[2], ctx->y, lw[3], cs[2], 1.0f, rows, E, 3 * E, 0, NULL));
-        /* attention in fp32, then its output quantised for the out-projection (one timed operator) */
-        OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads)) != 0 ? rc :
-                             vh_launch_convert_fp8(s, ctx->attn, ctx->y, (size_t)rows * E, 1.0f / as[1]));
-        OP(VIT_OP_OUT_PROJ, vh_launch_linear_fp8(s, ctx->x, 0, lw8[4], ctx->y, lw[5], cs[4], 1.0f, rows, E, E, 0, ctx->x));
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_fp8(s, ctx->x, lw[6], lw[7], ctx->y, 1.0f / as[2], rows, E, E, E, c->eps));
-        OP(VIT_OP_FC1, vh_launch_linear_fp8(s, ctx->hid, 2, lw8[8], ctx->y, lw[9], cs[8], 1.0f / as[3], rows, E, F, 1, NULL));
-        OP(VIT_OP_FC2, vh_launch_linear_fp8(s, ctx->x, 0, lw8[10], ctx->hid, lw[11], cs[10], 1.0f, rows, F, E, 0, ctx->x));
+        /* block-scaled fp8 GEMM operands: y, attn and hid hold MX tensors (values, then the scales, in the same
+         * allocations); qkv and the residual stream stay fp32; attention as in the other reduced modes */
+        float **lw = w + 4 + 12 * l;
+        void **l8 = ctx->w8 + 4 + 12 * l, **l8s = ctx->w8s + 4 + 12 * l;
+        char *ys = (char *)ctx->y + align_up((size_t)rows * E, 256), *as_ = (char *)ctx->attn + align_up((size_t)rows * E, 256);
+        char *hs = (char *)ctx->hid + align_up((size_t)rows * F, 256);
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[0], lw[1], ctx->y, ys, rows, E, E, c->eps));
+        OP(VIT_OP_QKV, vh_launch_linear_mx(s, ctx->qkv, NULL, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E, 0, NULL));
+        /* attention on fp16-rounded operands, fp32 out (into the idle MLP buffer), then quantised (one timed operator) */
+        OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                             vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
+        OP(VIT_OP_OUT_PROJ, vh_launch_linear_mx(s, ctx->x, NULL, l8[4], l8s[4], ctx->attn, as_, lw[5], rows, E, E, 0, ctx->x));
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[6], lw[7], ctx->y, ys, rows, E, E, c->eps));
+        OP(VIT_OP_FC1, vh_launch_linear_mx(s, ctx->hid, hs, l8[8], l8s[8], ctx->y, ys, lw[9], rows, E, F, 1, NULL));
+        OP(VIT_OP_FC2, vh_launch_linear_mx(s, ctx->x, NULL, l8[10], l8s[10], ctx->hid, hs, lw[11], rows, F, E, 0, ctx->x));
     }
     for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32_FP16X2; ++l) {
         /* the fp32 layer with the four projections on two fp16 parts / three products */
@@ -522,25 +499,16 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     }
     for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32 && !ctx->use_p3; ++l) {
         float **lw = w + 4 + 12 * l; /* ln1 w,b; in w,b; out w,b; ln2 w,b; fc1 w,b; fc2 w,b */
-        float *amax = ctx->calibrating ? ctx->d_amax + 4 * l : NULL; /* fp8 calibration: record max |GEMM input| */
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
-        if (amax)
-            TRY(vh_launch_absmax(s, ctx->y, (size_t)rows * E, amax + 0));
         void **l3 = ctx->w3 + 4 + 12 * l;   /* pre-split weight planes, when built */
         OP(VIT_OP_QKV, l3[2] ? vh_launch_linear_w3(s, ctx->qkv, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL)
                              : vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
         OP(VIT_OP_ATTENTION, vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-        if (amax)
-            TRY(vh_launch_absmax(s, ctx->attn, (size_t)rows * E, amax + 1));
         OP(VIT_OP_OUT_PROJ, l3[4] ? vh_launch_linear_w3(s, ctx->x, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x)
                                   : vh_launch_linear(s, ctx->x, lw[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
-        if (amax)
-            TRY(vh_launch_absmax(s, ctx->y, (size_t)rows * E, amax + 2));
         OP(VIT_OP_FC1, l3[8] ? vh_launch_linear_w3(s, ctx->hid, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL)
                              : vh_launch_linear(s, ctx->hid, lw[8], ctx->y, lw[9], rows, E, F, 1, NULL));
-        if (amax)
-            TRY(vh_launch_absmax(s, ctx->hid, (size_t)rows * F, amax + 3));
         OP(VIT_OP_FC2, l3[10] ? vh_launch_linear_w3(s, ctx->x, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x)
                               : vh_launch_linear(s, ctx->x, lw[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
     }
@@ -566,66 +534,6 @@ int vit_hip_read_tokens(vit_hip_ctx *ctx, int n, float *host_out)
     rc = vh_d2h(host_out, ctx->x, (size_t)n * ctx->tokens * ctx->cfg.embed_dim * sizeof(float),
                     ctx->stream);
     return rc ? rc : vh_stream_sync(ctx->stream);
-}
-
-/* FP8_GEMM calibration: run the fp32 path over n device-resident images (in chunks of
- * max_batch), record max |x| of the four GEMM inputs of every layer, and derive the
- * per-tensor activation scales (amax / 448) and the per-column rescale vectors. */
-int vit_hip_calibrate_fp8(vit_hip_ctx *ctx, const float *d_images, int n)
-{
-    int rc = 0;
-    if (!ctx || ctx->precision != VIT_PRECISION_FP8_GEMM || !d_images || n <= 0)
-        return 1;
-    if ((rc = vh_set_device(ctx->device)) != 0)
-        return rc;
-    const vit_config *c = &ctx->cfg;
-    const size_t per = (size_t)c->in_chans * c->img_size * c->img_size;
-    const int n_scales = 4 * c->depth;
-    static const int big[4] = {2, 4, 8, 10};
-    float *amax = (float *)malloc(sizeof(float) * (size_t)n_scales);
-    if (!amax)
-        return 4;
-    TRY(vh_memset(ctx->d_amax, 0, sizeof(float) * (size_t)n_scales, ctx->stream));
-    ctx->calibrating = 1;
-    for (int first = 0; first < n && rc == 0; first += ctx->max_batch) {
-        const int m = n - first < ctx->max_batch ? n - first : ctx->max_batch;
-        rc = vit_hip_forward_device(ctx, d_images + (size_t)first * per, m, NULL, NULL, ctx->stream);
-    }
-    ctx->calibrating = 0;
-    if (rc)
-        goto fail;
-    TRY(vh_d2h(amax, ctx->d_amax, sizeof(float) * (size_t)n_scales, ctx->stream));
-    TRY(vh_stream_sync(ctx->stream));
-    for (int l = 0; l < c->depth; ++l)
-        for (int k = 0; k < 4; ++k) {
-            const int idx = 4 + 12 * l + big[k];
-            const float a = amax[4 * l + k];
-            if (!(a == a) || a > 3.0e38f) { /* NaN / inf */
-                fprintf(stderr, "vit_hip_calibrate_fp8: layer %d input %d has a non-finite maximum\n", l, k);
-                rc = 6;
-                goto fail;
-            }
-            const float scale = a > 0.0f ? a / 448.0f : 1.0f;
-            ctx->act_scale[4 * l + k] = scale;
-            TRY(vh_launch_scale_vector(ctx->stream, ctx->colscale[idx], ctx->wscale[idx], scale,
-                                       (int)vit_config_tensor_size(c, idx + 1)));
-        }
-    TRY(vh_stream_sync(ctx->stream));
-    ctx->calibrated = 1;
-fail:
-    free(amax);
-    return rc;
-}
-
-/* The calibrated scales (host copy, [depth][4]: LN1 out, attention out, LN2 out, MLP hidden);
- * returns the count written, 0 before calibration. */
-int vit_hip_fp8_scales(const vit_hip_ctx *ctx, float *out, int capacity)
-{
-    if (!ctx || !ctx->calibrated || !out)
-        return 0;
-    const int n = 4 * ctx->cfg.depth < capacity ? 4 * ctx->cfg.depth : capacity;
-    memcpy(out, ctx->act_scale, sizeof(float) * (size_t)n);
-    return n;
 }
 
 int vit_hip_profile_enable(vit_hip_ctx *ctx, int max_forwards)

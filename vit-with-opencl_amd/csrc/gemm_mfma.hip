@@ -15,7 +15,6 @@
  *                   with the weights pre-split into planes (vh_launch_linear_w3) only the activations are split
  *   fp32, native    v_mfma_f32_32x32x2_f32: the ragged-N classifier, and everything under VIT_HIP_GEMM_FP32=native
  *   fp16 pairs      vh_launch_linear_h2 (opt-in emulation mode: two fp16 parts, three products)
- *   fp8 (e4m3)      v_mfma_f32_16x16x32_fp8_fp8 + per-column rescale (BASELINE config 5, opt-in)
  * Two kernel templates share one staging scheme: gemm_mf16_kernel (the 16x16x32 shapes) and
  * gemm_f32_kernel (native fp32, ragged N).
  *
@@ -56,7 +55,7 @@ constexpr int BK = 32;   /* 32-bit words per LDS row: 32 fp32 or 64 bf16 K eleme
 
 enum { A_ROWS = 0, A_PATCH = 1 };
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
-enum { K_F32 = 0, K_FP8 = 2 };   /* element kind of GEMM operands / output */
+enum { K_F32 = 0 };   /* element kind of GEMM operands / output */
 #define SGB_M 1   /* scheduled split loop: SGB_M MFMAs, then SGB_V VALU instructions, repeated (measured best of 1:1 .. 3:6) */
 #define SGB_V 2
 
@@ -89,9 +88,7 @@ struct Tile {
 struct GemmParams {
     const void *A, *W;        /* operands: fp32 or bf16, row-major [M][K] and [N][K] */
     const float *bias, *R, *pos;
-    const float *col_scale;   /* fp8 operands: a_scale * w_scale[n], multiplies the raw sum */
     float w_scale, inv_w_scale; /* fp16 weight parts: the power of two the weights were multiplied by, and its inverse */
-    float out_scale;          /* fp8 output: multiplier applied before the cast (1 / scale of the next input) */
     void *C;                  /* output: fp32 or bf16 */
     int M, N, K;
     int mtiles, ntiles;
@@ -358,11 +355,9 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     constexpr int BM = T::BM, BN = T::BN;
     constexpr int IT = BM / T::WM / 16, JT = BN / T::WN / 16;   /* 16x16 blocks per wave */
     constexpr int IC = IT < 4 ? IT : 4;                          /* A fragments split at a time */
-    constexpr bool FP8IN = INK == K_FP8;
-    constexpr int ES = FP8IN ? 1 : 4;
+    constexpr int ES = 4;
     constexpr int KE = 128 / ES;
-    static_assert(!(INK != K_F32 && AMODE == A_PATCH), "im2row loader is fp32 only");
-    static_assert(IT % IC == 0, "row blocks per wave");
+        static_assert(IT % IC == 0, "row blocks per wave");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -381,9 +376,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
     f32x4 acc[IT][JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-        /* fp8 operands carry scales: the sum is rescaled before the bias is added (epilogue) */
-        f32x4 bv = FP8IN ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
-                         : *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 16 * JT + j * 16 + 4 * q);
+        f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 16 * JT + j * 16 + 4 * q);
         if (NPL == 2)   /* fp16 weight parts carry a power-of-two scale: exact, undone in the epilogue */
             bv = bv * p.w_scale;
 #pragma unroll
@@ -399,29 +392,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
 
     auto compute = [&](int stage) {
         const float *ab = a_lane + stage * STG, *wb = w_lane + stage * STG;
-        if constexpr (FP8IN) {
-            /* 128 fp8 per LDS row = four 32-deep groups.  One ds_read_b128 (16 bytes) per lane
-             * feeds two MFMAs: lane group q contracts k = 64h + 16q + 8m .. +7 in MFMA (h, m),
-             * the same permutation for both operands. */
-            typedef long i64x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int ko = 4 * ((4 * hh + q) ^ swz);
-                i64x2 w[JT];
-#pragma unroll
-                for (int j = 0; j < JT; ++j)
-                    w[j] = __builtin_bit_cast(i64x2, *reinterpret_cast<const f32x4 *>(wb + j * 16 * BK + ko));
-#pragma unroll
-                for (int i = 0; i < IT; ++i) {
-                    const i64x2 a = __builtin_bit_cast(i64x2, *reinterpret_cast<const f32x4 *>(ab + i * 16 * BK + ko));
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int j = 0; j < JT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w[j][m], a[m], acc[i][j], 0, 0, 0);
-                }
-            }
-        } else if constexpr (SCHED) {
+        if constexpr (SCHED) {
             /* Fragment-grained pipeline inside the K step: group i issues the LDS reads of A
              * fragment i+2, splits fragment i+1 and runs the 6*JT MFMAs of fragment i, the
              * MFMA / VALU interleave pinned with sched_group_barrier (left alone, the compiler
@@ -477,7 +448,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            static_assert(FP8IN || SCHED, "fp32 operands use the scheduled loop");
+            static_assert(SCHED, "fp32 operands use the scheduled loop");
         }
     };
 
@@ -628,8 +599,6 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
             f32x4 v = acc[i][j];
             if (NPL == 2)
                 v = v * p.inv_w_scale;
-            if (FP8IN) /* undo the operand scales (per tensor for A, per output column for W), then the bias */
-                v = v * *reinterpret_cast<const f32x4 *>(p.col_scale + col) + *reinterpret_cast<const f32x4 *>(p.bias + col);
             if (EPI == EPI_GELU) {
                 const f32x2 lo = gelu_exact2(f32x2{v[0], v[1]}), hi = gelu_exact2(f32x2{v[2], v[3]});
                 v = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -638,12 +607,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WAVES_PER_SIMD) void gemm_mf16_kernel
                 v = *reinterpret_cast<const f32x4 *>(p.R + orow * p.N + col) + v;
             if (EPI == EPI_PATCH)
                 v = v + *reinterpret_cast<const f32x4 *>(posrow + col);
-            if (OUTK == K_FP8) {
-                *reinterpret_cast<unsigned *>(static_cast<unsigned char *>(p.C) + orow * p.N + col) =
-                    pack_fp8x4(v * p.out_scale);
-            } else {
-                *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + orow * p.N + col) = v;
-            }
+            *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + orow * p.N + col) = v;
         }
     }
 }
@@ -684,10 +648,10 @@ int launch_tile(hipStream_t st, GemmParams p)
 }
 
 /* Tile configurations (every configuration computes the same k order, so results are identical). */
-using Tile0 = Tile<128, 128, 2, 4>; /*  8 waves of 64x32, 2 workgroups per CU: ragged N (native fp32), fp8 small */
+using Tile0 = Tile<128, 128, 2, 4>; /*  8 waves of 64x32, 2 workgroups per CU: ragged N and small shapes (native fp32) */
 using Tile1 = Tile<128, 128, 2, 2>; /*  4 waves of 64x64, 2 workgroups per CU */
 using Tile3 = Tile<256, 256, 2, 4>; /*  8 waves of 128x64 */
-using Tile4 = Tile<256, 256, 4, 4>; /* 16 waves of 64x64: native fp32, fp8 */
+using Tile4 = Tile<256, 256, 4, 4>; /* 16 waves of 64x64: native fp32 */
 using Tile8 = Tile<256, 256, 4, 2>; /*  8 waves of 64x128 (pre-split weights: fewer A splits per wave) */
 using Tile9 = Tile<128, 128, 4, 1>; /*  4 waves of 32x128, 2 workgroups per CU */
 
@@ -751,30 +715,6 @@ extern "C" int vh_launch_linear(vh_stream_t s, float *output, const float *weigh
 
 namespace {
 
-/* fp8 (OCP e4m3) operands, fp32 accumulate.  Half the operand bytes of bf16 at the same MFMA
- * rate (non-scaled v_mfma_f32_16x16x32_fp8_fp8); tile choice as for bf16. */
-template <int EPI, int OUTK>
-int launch_fp8(hipStream_t st, const GemmParams &p)
-{
-    if (p.N % 256 == 0 && p.M >= 4096)
-        return launch_mf16<Tile4, A_ROWS, EPI, K_FP8, OUTK>(st, p);
-    return launch_mf16<Tile0, A_ROWS, EPI, K_FP8, OUTK>(st, p);
-}
-
-__global__ void convert_fp8_kernel(const float *__restrict__ in, unsigned char *__restrict__ out, size_t n, float mult)
-{
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i + 3 < n) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + i);
-        *reinterpret_cast<unsigned *>(out + i) = pack_fp8x4(v * mult);
-    } else {
-        for (size_t k = i; k < n; ++k) {
-            const f32x4 v = {in[k] * mult, 0.0f, 0.0f, 0.0f};
-            out[k] = (unsigned char)(pack_fp8x4(v) & 0xff);
-        }
-    }
-}
-
 __device__ __forceinline__ float block_max_256(float v, float *red)
 {
 #pragma unroll
@@ -786,28 +726,6 @@ __device__ __forceinline__ float block_max_256(float v, float *red)
     v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     return v;
-}
-
-/* One block per weight row: scale = max|w| / 448, w8 = fp8(w / scale). */
-__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const float *__restrict__ w, unsigned char *__restrict__ w8,
-                                                                float *__restrict__ row_scale, int K)
-{
-    __shared__ float red[4];
-    const float *src = w + (size_t)blockIdx.x * K;
-    float mx = 0.0f;
-    for (int k = threadIdx.x * 4; k < K; k += 1024) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + k);
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    }
-    mx = block_max_256(mx, red);
-    const float scale = mx > 0.0f ? mx / VH_FP8_MAX : 1.0f;
-    const float inv = 1.0f / scale;
-    if (threadIdx.x == 0)
-        row_scale[blockIdx.x] = scale;
-    for (int k = threadIdx.x * 4; k < K; k += 1024) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + k);
-        *reinterpret_cast<unsigned *>(w8 + (size_t)blockIdx.x * K + k) = pack_fp8x4(v * inv);
-    }
 }
 
 /* max |x| over a tensor into *amax (non-negative floats order like their bit patterns). */
@@ -824,13 +742,6 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ i
     mx = block_max_256(mx, red);
     if (threadIdx.x == 0 && mx == mx) /* NaNs are not a maximum */
         atomicMax(reinterpret_cast<unsigned *>(amax), __builtin_bit_cast(unsigned, mx));
-}
-
-__global__ void scale_vector_kernel(float *__restrict__ out, const float *__restrict__ in, float mult, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        out[i] = in[i] * mult;
 }
 
 } // namespace
@@ -977,28 +888,6 @@ extern "C" int vh_launch_linear_w3(vh_stream_t s, float *output, const void *wei
     return launch_planes<EPI_NONE, 3>(st, p, prefer_small);
 }
 
-extern "C" int vh_launch_convert_fp8(vh_stream_t s, const float *input, void *output, size_t count, float multiplier)
-{
-    if (!input || !output || count == 0)
-        return vh_fail(1, "vh_launch_convert_fp8: bad argument");
-    const size_t threads = (count + 3) / 4;
-    hipLaunchKernelGGL(convert_fp8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s,
-                       input, static_cast<unsigned char *>(output), count, multiplier);
-    VH_LAUNCH_CHECK("convert_fp8_kernel");
-    return 0;
-}
-
-extern "C" int vh_launch_quantize_rows_fp8(vh_stream_t s, const float *weight, void *weight_fp8, float *row_scale,
-                                           int rows, int cols)
-{
-    if (!weight || !weight_fp8 || !row_scale || rows <= 0 || cols <= 0 || cols % 4 != 0)
-        return vh_fail(1, "vh_launch_quantize_rows_fp8: bad argument (cols must be a multiple of 4)");
-    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(rows), dim3(256), 0, (hipStream_t)s, weight,
-                       static_cast<unsigned char *>(weight_fp8), row_scale, cols);
-    VH_LAUNCH_CHECK("quantize_rows_fp8_kernel");
-    return 0;
-}
-
 extern "C" int vh_launch_absmax(vh_stream_t s, const float *input, size_t count, float *amax)
 {
     if (!input || !amax || count == 0)
@@ -1011,40 +900,6 @@ extern "C" int vh_launch_absmax(vh_stream_t s, const float *input, size_t count,
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, input, count, amax);
     VH_LAUNCH_CHECK("absmax_kernel");
     return 0;
-}
-
-extern "C" int vh_launch_scale_vector(vh_stream_t s, float *output, const float *input, float multiplier, int count)
-{
-    if (!output || !input || count <= 0)
-        return vh_fail(1, "vh_launch_scale_vector: bad argument");
-    hipLaunchKernelGGL(scale_vector_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)s, output, input,
-                       multiplier, count);
-    VH_LAUNCH_CHECK("scale_vector_kernel");
-    return 0;
-}
-
-extern "C" int vh_launch_linear_fp8(vh_stream_t s, void *output, int output_kind, const void *weight,
-                                    const void *input, const float *bias, const float *col_scale, float out_multiplier,
-                                    int rowA, int colA, int colB, int doGelu, const float *residual)
-{
-    if (!output || !weight || !input || !bias || !col_scale)
-        return vh_fail(1, "vh_launch_linear_fp8: null pointer argument");
-    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % 128 != 0 || colB % 128 != 0)
-        return vh_fail(1, "vh_launch_linear_fp8: needs colA %% 128 == 0 and colB %% 128 == 0 (%d,%d,%d)", rowA, colA, colB);
-    if ((output_kind != 0 && output_kind != 2) || (doGelu && residual) || (residual && output_kind != 0))
-        return vh_fail(1, "vh_launch_linear_fp8: unsupported output kind / epilogue combination");
-    GemmParams p = {};
-    p.A = input; p.W = weight; p.bias = bias; p.R = residual; p.C = output;
-    p.col_scale = col_scale; p.out_scale = out_multiplier;
-    p.M = rowA; p.N = colB; p.K = colA;
-    if ((((uintptr_t)output | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)col_scale) & 15) != 0)
-        return vh_fail(1, "vh_launch_linear_fp8: pointers must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)s;
-    if (doGelu)
-        return output_kind == 2 ? launch_fp8<EPI_GELU, K_FP8>(st, p) : launch_fp8<EPI_GELU, K_F32>(st, p);
-    if (residual)
-        return launch_fp8<EPI_RESID, K_F32>(st, p);
-    return output_kind == 2 ? launch_fp8<EPI_NONE, K_FP8>(st, p) : launch_fp8<EPI_NONE, K_F32>(st, p);
 }
 
 namespace {

@@ -1,0 +1,368 @@
+/*
+ * gemm_mx.hip -- the four big projections on block-scaled fp8 ("MX": OCP microscaling, e4m3 elements, one
+ * e8m0 power-of-two scale per 32 consecutive K elements) with v_mfma_scale_f32_16x16x128_f8f6f4, which runs at
+ * twice the bf16 rate (the non-scaled fp8 MFMA of gemm_mfma.hip runs AT the bf16 rate).  BASELINE config 5
+ * ("fp8 weights (CDNA4 fp8 MFMA)"); no reference counterpart (the reference is fp32 throughout: ll.cl:7-86,
+ * multihead.cl:3-63).  Opt-in precision VIT_PRECISION_MXFP8_GEMM.
+ *
+ * Operand format ("MX planes"), weights [N][K] and activations [rows][K] alike:
+ *     values[K/128][rows][128]  e4m3 bytes     K step, row, element
+ *     scales[K/128][4][rows]    e8m0 bytes     K step, lane group, row
+ * so a 16-row fragment of one K step is 2 KiB contiguous.  Block b (0..3) of a row's K step = its elements
+ * 32b .. 32b+31.  The instruction's operand map, measured on the device (no ISA text at hand; tests pin it with
+ * a numpy statement): lane l = (row l & 15, group j = l >> 4) supplies 32 bytes; its bytes 0-15 belong,
+ * together with bytes 0-15 of group j ^ 1, to one scale block, its bytes 16-31 likewise to another; the scale of
+ * the block {groups 2m, 2m+1; byte half h} is byte 0 of the scale VGPR of lane group m + 2h.  Hence
+ *     lane (row, j):  bytes 0-15  = block 2(j>>1)   , half (j & 1)   -> offset 64(j>>1) + 16(j&1)
+ *                     bytes 16-31 = block 2(j>>1)+1 , same half      -> + 32
+ *                     scale VGPR  = scale of block 2(j&1) + (j>>1)  -> scales[..][j][row] holds exactly that
+ * (two 16-byte loads and one byte load per fragment and lane, no shuffling).  A and B operands pair up by
+ * (lane group, byte), so any assignment works as long as both sides use the same one.
+ *
+ * Kernel structure = gemm_p3.hip's: tile 256 x 256 (or 128 x 128), every wave owns 32 rows; A fragments go
+ * HBM/L2 -> VGPR directly (coalesced thanks to the format), double-buffered one K step ahead; W goes by LDS-DMA
+ * into [256][128 B] rows (16-byte chunks swizzled c ^ ((r >> 1) & 7)) plus its 1 KiB of scales, two stages; W
+ * fragments are taken through a ring of four in registers; one barrier per K step (128 k = 32 MFMAs per wave)
+ * before the last ring's worth of MFMAs.  The same column permutation gives a lane eight consecutive output
+ * columns: a planes epilogue quantises (block maximum over the four lanes of a row's 32 columns by two
+ * shuffles) and stores 8 bytes per lane, plus the scale byte from one lane in four.
+ */
+#include "kernelHandler.h"
+#include "vit_kernels.h"
+#include "gemm_common.h"
+
+#include <cstdint>
+#include <cstdlib>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+typedef const __attribute__((address_space(1))) char *gchar_t;
+typedef const __attribute__((address_space(1))) f32x4 *gvec_t;
+typedef const __attribute__((address_space(1))) unsigned char *gbyte_t;
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2 };
+enum { OUT_F32 = 0, OUT_MX = 1 };
+
+struct MxParams {
+    const char *A, *As;       /* activation values [K/128][a_rows][128], scales [K/128][4][a_rows] */
+    const char *W, *Ws;       /* weight values [K/128][N][128], scales [K/128][4][N] */
+    const float *bias, *R;
+    void *C, *Cs;             /* fp32 [a_rows][N]; or MX values [N/128][a_rows][128] + scales [N/128][4][a_rows] */
+    int row_begin, row_end, N, K, a_rows, mtiles, ntiles;
+};
+
+/* scale byte and multiplier of one 32-element block from its largest magnitude: the smallest power of two
+ * that brings the block inside e4m3's range, 2^E with E = ceil(log2(amax / 448)).  (OCP MX v1.0 suggests
+ * floor(log2(amax)) - 8, which lets maxima with a significand above 1.75 saturate at 448 -- a 12.5 % clip of the
+ * block's largest element; rounding the exponent up instead costs at most one bit of the smallest ones.)  Zero /
+ * subnormal maxima take the smallest scale the multiplier can undo. */
+__device__ __forceinline__ void mx_block_scale(float amax, unsigned &scale_byte, float &mult)
+{
+    const unsigned bits = __builtin_bit_cast(unsigned, amax);
+    int e = (int)((bits >> 23) & 0xff) - 127 - 8 + ((bits & 0x7fffff) > 0x600000 ? 1 : 0);   /* significand > 1.75 */
+    e = e < -126 ? -126 : e;
+    scale_byte = (unsigned)(e + 127);
+    mult = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);                    /* 2^-e, exact */
+}
+
+template <int NW, int BN, int EPI, int OUTK>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
+{
+    constexpr int BM = 32 * NW, JT = BN / 16, RING = 4;
+    constexpr int VALS = BN * 128;                  /* bytes of W values per stage */
+    constexpr int STAGE = VALS + 4 * BN;            /* + its scales [4][BN] */
+    constexpr int PW = BN / 8 / NW;                 /* 1-KiB value pieces (8 rows x 128 B) per wave and stage */
+    static_assert(JT % RING == 0 && (BN / 8) % NW == 0 && 4 * BN <= 1024, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tile = xcd_tile(blockIdx.x, p.mtiles * p.ntiles);
+    const int m0 = p.row_begin + (tile / p.ntiles) * BM;
+    const int n0 = (tile % p.ntiles) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, j4 = lane >> 4;
+
+    /* A fragment i: rows m0 + 32 wave + 16 i + l15 (clamped), bytes 64 (j>>1) + 16 (j&1) and + 32 */
+    unsigned arow[2], aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = (unsigned)min(m0 + 32 * wave + 16 * i + l15, p.row_end - 1);
+        aoff[i] = arow[i] * 128u + 64u * (j4 >> 1) + 16u * (j4 & 1);
+    }
+    const size_t a_step = (size_t)p.a_rows * 128, as_step = (size_t)p.a_rows * 4;
+    const size_t w_step = (size_t)p.N * 128, ws_step = (size_t)p.N * 4;
+
+    /* W DMA: value piece pc = rows 8pc .. 8pc+7 (lane fills physical chunk lane & 7 of row 8pc + (lane >> 3) with
+     * logical chunk phys ^ ((row >> 1) & 7)); the scales [4][BN] of the stage are one more piece (BN = 256) */
+    /* (row >> 1) & 7 with row = 8 pc + (lane >> 3): = 4 (pc & 1) + ((lane >> 4) & 3) */
+    const gchar_t wtile = (gchar_t)p.W + (size_t)n0 * 128;
+    auto dma_w = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int pc = wave * PW + i;
+            gchar_t src = wtile + (size_t)kt * w_step + (size_t)pc * 1024;
+            asm volatile("" : "+s"(src));
+            const unsigned off = (unsigned)(lane >> 3) * 128u + 16u * ((lane & 7) ^ (4 * (pc & 1) + ((lane >> 4) & 3)));
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(smem + stage * STAGE + pc * 1024), 16, 0, 0);
+        }
+        if (wave == 0) {   /* scales: 4 runs of BN bytes -> [4][BN] in LDS: 16 bytes per lane (BN = 256), lanes 0..BN/4-1 */
+            if (lane < BN / 4) {
+                const int jj = lane / (BN / 16), within = lane - jj * (BN / 16);
+                gchar_t src = (gchar_t)p.Ws + (size_t)kt * ws_step + (size_t)jj * p.N + n0 + 16 * within;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + stage * STAGE + VALS), 16, 0, 0);
+            }
+        }
+    };
+
+    /* W fragment j = 2s + b, MFMA row l15 = LDS row 32s + 8 (l15 >> 2) + 4b + (l15 & 3); chunk c of row r sits at
+     * c ^ ((r >> 1) & 7); this lane's chunks are 4 (j4 >> 1) + (j4 & 1) and + 2 */
+    const int rl = 8 * (l15 >> 2) + (l15 & 3);
+    const int c0 = 4 * (j4 >> 1) + (j4 & 1);
+    unsigned wlo[2], whi[2], wsc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int r = rl + 4 * b, sw = (r >> 1) & 7;
+        wlo[b] = (unsigned)r * 128u + 16u * (c0 ^ sw);
+        whi[b] = (unsigned)r * 128u + 16u * ((c0 + 2) ^ sw);
+        wsc[b] = (unsigned)VALS + (unsigned)j4 * BN + (unsigned)r;
+    }
+
+    f32x4 acc[2][JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + n0 + 32 * (j >> 1) + 8 * j4 + 4 * (j & 1));
+        acc[0][j] = bv;
+        acc[1][j] = bv;
+    }
+
+    /* a fragment = two 16-byte halves (kept apart until the MFMA call) and the lane's scale byte */
+    i32x4 a0l[2], a0h[2], a1l[2], a1h[2], wl[RING], wh[RING];
+    int a0s[2], a1s[2], ws[RING];
+
+    auto load_a = [&](i32x4 (&al)[2], i32x4 (&ah)[2], int (&as)[2], int kt) {
+        gchar_t vb = (gchar_t)p.A + (size_t)kt * a_step;
+        gbyte_t sb = (gbyte_t)p.As + (size_t)kt * as_step + (size_t)j4 * p.a_rows;
+        asm volatile("" : "+s"(vb));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            al[i] = __builtin_bit_cast(i32x4, *reinterpret_cast<gvec_t>(vb + aoff[i]));
+            ah[i] = __builtin_bit_cast(i32x4, *reinterpret_cast<gvec_t>(vb + aoff[i] + 32));
+            as[i] = sb[arow[i]];
+        }
+    };
+    auto read_w = [&](int slot, const char *stage, int j) {
+        const int b = j & 1, s = j >> 1;
+        wl[slot] = __builtin_bit_cast(i32x4, *reinterpret_cast<const f32x4 *>(stage + wlo[b] + s * 32 * 128));
+        wh[slot] = __builtin_bit_cast(i32x4, *reinterpret_cast<const f32x4 *>(stage + whi[b] + s * 32 * 128));
+        ws[slot] = *reinterpret_cast<const unsigned char *>(stage + wsc[b] + s * 32);
+    };
+    /* The instruction through inline asm with the accumulator tied ("+v"): with the builtin, hipcc (ROCm 7.2) does
+     * not tie D to C for the scaled form, renames all 128 accumulators every K step and spills 300+ registers.
+     * What the compiler does not do for an asm statement (guide 5.7) is handled here: `s_nop 1` in front covers a
+     * VALU-written operand; the statements are volatile with a memory clobber, so MFMAs and LDS reads keep their
+     * source order; a fragment slot is refilled only after the NEXT fragment's MFMAs (two MFMAs behind its last
+     * reader); the epilogue waits out the last MFMA with explicit s_nops. */
+    auto mfma_frag = [&](const i32x4 (&al)[2], const i32x4 (&ah)[2], const int (&as)[2], int slot, int j) {
+        const i32x8 wv = __builtin_shufflevector(wl[slot], wh[slot], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  /* D[n][m]: W fragment as the MFMA's A operand */
+            const i32x8 av = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7);
+            asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+                         : "+v"(acc[i][j])
+                         : "v"(wv), "v"(av), "v"(ws[slot]), "v"(as[i])
+                         : "memory");
+        }
+    };
+
+    const int nk = p.K / 128;
+    auto step = [&](const i32x4 (&ul)[2], const i32x4 (&uh)[2], const int (&us)[2], i32x4 (&nl)[2], i32x4 (&nh)[2], int (&ns)[2], int kt) {
+        const char *cur = smem + (kt & 1) * STAGE, *nxt = smem + ((kt + 1) & 1) * STAGE;
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+        load_a(nl, nh, ns, more1 ? kt + 1 : kt);   /* unconditional (no copies at a join): the last step re-reads its own */
+#pragma unroll
+        for (int f = 0; f <= JT - RING; ++f) {
+            mfma_frag(ul, uh, us, f % RING, f);
+            read_w((f + RING - 1) % RING, cur, f + RING - 1);   /* the slot fragment f-1 was in */
+        }
+        __syncthreads();   /* stage kt read by every wave (its last fragments are in registers); stage kt+1 has landed */
+        if (more2)
+            dma_w(kt & 1, kt + 2);
+#pragma unroll
+        for (int f = JT - RING + 1; f < JT; ++f) {
+            mfma_frag(ul, uh, us, f % RING, f);
+            read_w((f + RING - 1) % RING, nxt, f + RING - 1 - JT);   /* unconditional: behind the last step it reads a stage nobody uses */
+        }
+    };
+
+    dma_w(0, 0);
+    load_a(a0l, a0h, a0s, 0);
+    __syncthreads();
+    if (nk > 1)
+        dma_w(1, 1);
+#pragma unroll
+    for (int f = 0; f < RING - 1; ++f)
+        read_w(f, smem, f);
+    for (int kt = 0; kt < nk; kt += 2) {   /* nk is even (launcher) */
+        step(a0l, a0h, a0s, a1l, a1h, a1s, kt);
+        step(a1l, a1h, a1s, a0l, a0h, a0s, kt + 1);
+    }
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   /* the last MFMA's result, before ordinary code reads it */
+
+    /* Epilogue: fragment pair (2s, 2s+1) of row block i = 8 consecutive columns n0 + 32s + 8 j4 .. +7 of one row */
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + 32 * wave + 16 * i + l15;
+        const bool live = row < p.row_end;
+#pragma unroll
+        for (int s = 0; s < JT / 2; ++s) {
+            const int col = n0 + 32 * s + 8 * j4;
+            f32x4 lo = acc[i][2 * s], hi = acc[i][2 * s + 1];
+            if (EPI == EPI_GELU) {
+                const f32x2 g0 = gelu_exact2(f32x2{lo[0], lo[1]}), g1 = gelu_exact2(f32x2{lo[2], lo[3]});
+                const f32x2 g2 = gelu_exact2(f32x2{hi[0], hi[1]}), g3 = gelu_exact2(f32x2{hi[2], hi[3]});
+                lo = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                hi = f32x4{g2[0], g2[1], g3[0], g3[1]};
+            }
+            if (EPI == EPI_RESID && live) {
+                const float *rp = p.R + (size_t)row * p.N + col;
+                lo = *reinterpret_cast<const f32x4 *>(rp) + lo;
+                hi = *reinterpret_cast<const f32x4 *>(rp + 4) + hi;
+            }
+            if (OUTK == OUT_MX) {
+                /* the row's 32 columns n0 + 32s .. +31 = one scale block, held by the four lanes l15 + 16 j */
+                float amax = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    amax = fmaxf(amax, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+                amax = fmaxf(amax, __shfl_xor(amax, 16));
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                unsigned sbyte;
+                float mult;
+                mx_block_scale(amax, sbyte, mult);
+                if (live) {
+                    const int ks = (n0 + 32 * s) >> 7, blk = ((n0 + 32 * s) >> 5) & 3;
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2 *>(static_cast<char *>(p.C) + ((size_t)ks * p.a_rows + row) * 128 + 32 * blk + 8 * j4) =
+                        u32x2{pack_fp8x4(lo * mult), pack_fp8x4(hi * mult)};
+                    if (j4 == 0)   /* scales[ks][lane group of block blk][row]: block b is read by lane group 2 (b & 1) + (b >> 1) */
+                        static_cast<unsigned char *>(p.Cs)[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * p.a_rows + row] = (unsigned char)sbyte;
+                }
+            } else if (live) {
+                float *cp = static_cast<float *>(p.C) + (size_t)row * p.N + col;
+                *reinterpret_cast<f32x4 *>(cp) = lo;
+                *reinterpret_cast<f32x4 *>(cp + 4) = hi;
+            }
+        }
+    }
+}
+
+template <int NW, int BN, int EPI, int OUTK>
+int launch_mx_tile(hipStream_t st, MxParams p)
+{
+    constexpr int LDS = 2 * (BN * 128 + 4 * BN);
+    VH_SET_LDS_ONCE((gemm_mx_kernel<NW, BN, EPI, OUTK>), LDS);
+    p.mtiles = (p.row_end - p.row_begin + 32 * NW - 1) / (32 * NW);
+    p.ntiles = p.N / BN;
+    hipLaunchKernelGGL((gemm_mx_kernel<NW, BN, EPI, OUTK>), dim3(p.mtiles * p.ntiles), dim3(64 * NW), LDS, st, p);
+    VH_LAUNCH_CHECK("gemm_mx_kernel");
+    return 0;
+}
+
+template <int EPI, int OUTK>
+int launch_mx(hipStream_t st, const MxParams &p, int small_only)
+{
+    const int rows = p.row_end - p.row_begin;
+    const int num_cus = vh_device_cus(vh_current_device());
+    const int ntiles = p.N / 256, mtiles = (rows + 255) / 256;
+    const long tiles = (long)mtiles * ntiles;
+    if (p.N % 256 != 0 || small_only || 2 * tiles < 5 * (long)num_cus)
+        return launch_mx_tile<4, 128, EPI, OUTK>(st, p);
+    const long full = tiles / num_cus, rem = tiles % num_cus;
+    const int rows_big = (int)(full * num_cus / ntiles) * 256;
+    if (rem == 0 || 4 * rem > 3 * num_cus || rows_big <= 0 || rows_big >= rows)
+        return launch_mx_tile<8, 256, EPI, OUTK>(st, p);
+    MxParams big = p, rest = p;
+    big.row_end = p.row_begin + rows_big;
+    rest.row_begin = big.row_end;
+    const int rc = launch_mx_tile<8, 256, EPI, OUTK>(st, big);
+    return rc ? rc : launch_mx_tile<4, 128, EPI, OUTK>(st, rest);
+}
+
+/* fp32 [rows][K] -> MX planes: one thread per (row, 32-element block) */
+__global__ void quantize_mx_rows_kernel(const float *__restrict__ in, char *__restrict__ values, unsigned char *__restrict__ scales,
+                                        int rows, int K)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = K >> 5;
+    if (idx >= (size_t)rows * nb)
+        return;
+    const int row = (int)(idx / nb), blkidx = (int)(idx - (size_t)row * nb);
+    const float *src = in + (size_t)row * K + 32 * blkidx;
+    f32x4 v[8];
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = *reinterpret_cast<const f32x4 *>(src + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            amax = fmaxf(amax, fabsf(v[i][e]));
+    }
+    unsigned sbyte;
+    float mult;
+    mx_block_scale(amax, sbyte, mult);
+    const int ks = blkidx >> 2, blk = blkidx & 3;
+    unsigned *dst = reinterpret_cast<unsigned *>(values + ((size_t)ks * rows + row) * 128 + 32 * blk);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        dst[i] = pack_fp8x4(v[i] * mult);
+    scales[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * rows + row] = (unsigned char)sbyte;
+}
+
+} // namespace
+
+extern "C" int vh_launch_quantize_mx_rows(vh_stream_t s, const float *input, void *values, void *scales, int rows, int cols)
+{
+    if (!input || !values || !scales || rows <= 0 || cols <= 0 || cols % 128 != 0 ||
+        (((uintptr_t)input | (uintptr_t)values) & 15))
+        return vh_fail(1, "vh_launch_quantize_mx_rows: bad argument (cols %% 128 == 0, 16-byte aligned pointers)");
+    const size_t threads = (size_t)rows * (cols / 32);
+    hipLaunchKernelGGL(quantize_mx_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, input,
+                       static_cast<char *>(values), static_cast<unsigned char *>(scales), rows, cols);
+    VH_LAUNCH_CHECK("quantize_mx_rows_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_linear_mx(vh_stream_t s, void *output, void *output_scales, const void *weight_values,
+                                   const void *weight_scales, const void *input_values, const void *input_scales,
+                                   const float *bias, int rowA, int colA, int colB, int doGelu, const float *residual)
+{
+    if (!output || !weight_values || !weight_scales || !input_values || !input_scales || !bias)
+        return vh_fail(1, "vh_launch_linear_mx: null pointer argument");
+    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % 256 != 0 || colB % 128 != 0)
+        return vh_fail(1, "vh_launch_linear_mx: needs colA %% 256 == 0 and colB %% 128 == 0 (%d,%d,%d)", rowA, colA, colB);
+    if ((doGelu && residual) || (residual && output_scales))
+        return vh_fail(1, "vh_launch_linear_mx: unsupported epilogue combination");
+    if ((((uintptr_t)output | (uintptr_t)weight_values | (uintptr_t)input_values | (uintptr_t)bias | (uintptr_t)residual |
+          (uintptr_t)weight_scales) & 15) != 0)
+        return vh_fail(1, "vh_launch_linear_mx: pointers must be 16-byte aligned");
+    if ((size_t)rowA * 128 > 0xffffffffull)
+        return vh_fail(1, "vh_launch_linear_mx: rowA=%d too large", rowA);
+    MxParams p = {};
+    p.A = static_cast<const char *>(input_values); p.As = static_cast<const char *>(input_scales);
+    p.W = static_cast<const char *>(weight_values); p.Ws = static_cast<const char *>(weight_scales);
+    p.bias = bias; p.R = residual; p.C = output; p.Cs = output_scales;
+    p.row_begin = 0; p.row_end = rowA; p.a_rows = rowA; p.N = colB; p.K = colA;
+    hipStream_t st = (hipStream_t)s;
+    const int small_only = residual && colA < 2048;
+    if (doGelu)
+        return output_scales ? launch_mx<EPI_GELU, OUT_MX>(st, p, small_only) : launch_mx<EPI_GELU, OUT_F32>(st, p, small_only);
+    if (residual)
+        return launch_mx<EPI_RESID, OUT_F32>(st, p, small_only);
+    return output_scales ? launch_mx<EPI_NONE, OUT_MX>(st, p, small_only) : launch_mx<EPI_NONE, OUT_F32>(st, p, small_only);
+}

@@ -54,6 +54,9 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 typedef const __attribute__((address_space(1))) char *gchar_t;     /* global-memory bytes (never flat) */
 typedef const __attribute__((address_space(1))) f32x4 *gvec_t;
 
+#ifndef P1_KG
+#define P1_KG 2   /* one-part operands: 32-deep K groups per LDS stage (one barrier per 32 * P1_KG k) */
+#endif
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2 };
 enum { OUT_F32 = 0, OUT_PLANES = 1 };
 
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
     auto step = [&](const frag_t (&au)[KG][2][NPL], frag_t (&al)[KG][2][NPL], int kt) {
         const char *cur = smem + (kt & 1) * STAGE, *nxt = smem + ((kt + 1) & 1) * STAGE;
         const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-        if (more1 && !(LAB & 4))
-            load_a(al, kt + 1);
+        if (!(LAB & 4))
+            load_a(al, more1 ? kt + 1 : kt);   /* unconditional (no copies at a join): the last step re-reads its own */
 #pragma unroll
         for (int f = 0; f <= F - RING; ++f) {
             if (!(LAB & 1) || kt == 0)
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
 template <int NW, int BN, int EPI, int OUTK, int NPL>
 int launch_p3_tile(hipStream_t st, P3Params p)
 {
-    constexpr int LDS = 2 * (NPL == 3 ? 1 : 2) * NPL * BN * 64;
+    constexpr int LDS = 2 * (NPL == 3 ? 1 : P1_KG) * NPL * BN * 64;
     VH_SET_LDS_ONCE((gemm_p3_kernel<NW, BN, EPI, OUTK, NPL>), LDS);
     p.mtiles = (p.row_end - p.row_begin + 32 * NW - 1) / (32 * NW);
     p.ntiles = p.N / BN;
@@ -410,7 +413,7 @@ extern "C" int vh_launch_linear_planes(vh_stream_t s, void *output, int output_p
         return vh_fail(1, "vh_launch_linear_planes: null pointer argument");
     if (parts != 1 && parts != 3)
         return vh_fail(1, "vh_launch_linear_planes: parts must be 3 (exact fp32 split) or 1 (bf16 operands)");
-    const int kstep = parts == 3 ? 64 : 128;   /* two LDS stages per loop iteration */
+    const int kstep = parts == 3 ? 64 : 64 * P1_KG;   /* two LDS stages per loop iteration */
     if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % kstep != 0 || colB % 128 != 0)
         return vh_fail(1, "vh_launch_linear_planes: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", kstep, rowA, colA, colB);
     if ((doGelu && residual) || (residual && output_planes))

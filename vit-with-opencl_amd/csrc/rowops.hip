@@ -36,7 +36,7 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 /* NV = 16-byte chunks per lane; handles embed_dim <= 256*NV, embed_dim % 4 == 0. */
-template <int NV, int OUTK> /* OUTK: 0 fp32, 2 fp8 (scaled by out_mult) */
+template <int NV, int OUTK> /* OUTK: 0 fp32 rows */
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta,
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
     f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(out) + (size_t)row * out_stride);
-    unsigned *dst8 = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(out) + (size_t)row * out_stride);
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
         const int idx = c * 64 + lane;
@@ -83,11 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 y[e] = (x[c][e] - mean) * inv_std * g[e] + bb[e];
-            if (OUTK == 2) { /* the only consumer is an fp8-operand GEMM: scale and round once, here */
-                dst8[idx] = pack_fp8x4(y * out_mult);
-            } else {
-                dst[idx] = y;
-            }
+            dst[idx] = y;
         }
     }
 }
@@ -162,6 +157,91 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float
                 *reinterpret_cast<const f32x4 *>(ln_lds + pc * 1024 + 16 * lane);
 }
 
+/* LayerNorm whose only consumer is the block-scaled fp8 GEMM (gemm_mx.hip): one wave per row as above; a lane
+ * holds 4 consecutive values, the 8 lanes 8m .. 8m+7 one 32-element scale block (three shuffles for its maximum);
+ * values and scales go through an LDS image in the MX planes' own order ([K step][16 rows][128 B], then
+ * [K step][4][16 rows] scale bytes) so that the global stores are contiguous 2 KiB / 16-byte runs. */
+template <int NV>
+__global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float *__restrict__ in, const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta, char *__restrict__ values,
+                                                                    unsigned char *__restrict__ scales, int rows, int E,
+                                                                    long in_stride, double eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char ln_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * LN3_ROWS, row = row0 + wave;
+    const int nvec = E >> 2, ksteps = E >> 7;
+    char *lds_scales = ln_lds + ksteps * LN3_ROWS * 128;
+    if (row < rows) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)row * in_stride);
+        f32x4 x[NV];
+        float sum = 0.0f, sq = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int idx = c * 64 + lane;
+            if (idx < nvec) {
+                x[c] = src[idx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sum += x[c][e];
+                    sq += x[c][e] * x[c][e];
+                }
+            }
+        }
+        sum = wave_sum(sum);
+        sq = wave_sum(sq);
+        const float mean = sum / (float)E;
+        const float var = sq / (float)E - mean * mean;
+        const float inv_std = 1.0f / sqrtf((float)((double)var + eps));
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+        const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int idx = c * 64 + lane;
+            if (idx < nvec) {          /* E % 128 == 0: whole groups of 8 lanes are in or out together */
+                const f32x4 g = g4[idx], bb = b4[idx];
+                f32x4 y;
+                float amax = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = (x[c][e] - mean) * inv_std * g[e] + bb[e];
+                    amax = fmaxf(amax, fabsf(y[e]));
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 1));
+                amax = fmaxf(amax, __shfl_xor(amax, 2));
+                amax = fmaxf(amax, __shfl_xor(amax, 4));
+                const unsigned abits = __builtin_bit_cast(unsigned, amax);   /* as mx_block_scale (gemm_mx.hip) */
+                int ex = (int)((abits >> 23) & 0xff) - 127 - 8 + ((abits & 0x7fffff) > 0x600000 ? 1 : 0);
+                ex = ex < -126 ? -126 : ex;
+                const float mult = __builtin_bit_cast(float, (unsigned)(127 - ex) << 23);
+                const int k = 4 * idx, ks = k >> 7, blk = (k >> 5) & 3;
+                *reinterpret_cast<unsigned *>(ln_lds + (ks * LN3_ROWS + wave) * 128 + (k & 127)) = pack_fp8x4(y * mult);
+                if ((lane & 7) == 0)
+                    lds_scales[(ks * 4 + 2 * (blk & 1) + (blk >> 1)) * LN3_ROWS + wave] = (char)(ex + 127);
+            }
+        }
+    }
+    __syncthreads();
+    /* copy-out: values piece = half a K step's image (8 rows x 128 B = 1 KiB, lane moves 16 B of row l / 8);
+     * scales: one 16-byte run (16 rows) per (K step, lane group) */
+    const int vpieces = ksteps * 2;
+    for (int pc = wave; pc < vpieces; pc += LN3_ROWS) {
+        const int ks = pc >> 1, r = 8 * (pc & 1) + (lane >> 3);
+        if (row0 + r < rows)
+            *reinterpret_cast<f32x4 *>(values + ((size_t)ks * rows + row0 + r) * 128 + 16 * (lane & 7)) =
+                *reinterpret_cast<const f32x4 *>(ln_lds + (ks * LN3_ROWS + r) * 128 + 16 * (lane & 7));
+    }
+    if (threadIdx.x < ksteps * 4) {
+        unsigned char *dst = scales + (size_t)threadIdx.x * rows + row0;
+        const char *srcs = lds_scales + threadIdx.x * LN3_ROWS;
+        if (row0 + LN3_ROWS <= rows && (((uintptr_t)dst) & 15) == 0)
+            *reinterpret_cast<f32x4 *>(dst) = *reinterpret_cast<const f32x4 *>(srcs);
+        else
+            for (int r = 0; r < LN3_ROWS && row0 + r < rows; ++r)
+                dst[r] = (unsigned char)srcs[r];
+    }
+}
+
 constexpr int SM_THREADS = 256;
 constexpr int SM_MAX_PER_THREAD = 8; /* rows up to 2048 entries stay in registers */
 
@@ -228,10 +308,7 @@ static int launch_layer_norm(vh_stream_t s, const float *input, const float *wei
                        rows, embed_dim, in_row_stride, out_row_stride, eps, out_mult)
 #define VH_LN(NV)                                                                                   \
     do {                                                                                            \
-        if (out_kind == 2)                                                                          \
-            VH_LN_K(NV, 2);                                                                         \
-        else                                                                                        \
-            VH_LN_K(NV, 0);                                                                         \
+        VH_LN_K(NV, 0);                                                                             \
     } while (0)
     if (nv <= 3) VH_LN(3);
     else if (nv <= 4) VH_LN(4);
@@ -296,12 +373,31 @@ extern "C" int vh_launch_layer_norm_p3(vh_stream_t s, const float *input, const 
     return vh_launch_layer_norm_planes(s, input, weight, bias, out_planes, 3, rows, embed_dim, in_row_stride, eps);
 }
 
-extern "C" int vh_launch_layer_norm_fp8(vh_stream_t s, const float *input, const float *weight,
-                                        const float *bias, void *output, float out_multiplier, int rows,
-                                        int embed_dim, long in_row_stride, long out_row_stride, double eps)
+extern "C" int vh_launch_layer_norm_mx(vh_stream_t s, const float *input, const float *weight, const float *bias,
+                                       void *out_values, void *out_scales, int rows, int embed_dim, long in_row_stride,
+                                       double eps)
 {
-    return launch_layer_norm(s, input, weight, bias, output, 2, out_multiplier, rows, embed_dim, in_row_stride,
-                             out_row_stride, eps);
+    if (!input || !weight || !bias || !out_values || !out_scales)
+        return vh_fail(1, "vh_launch_layer_norm_mx: null pointer argument");
+    if (rows <= 0 || embed_dim <= 0 || embed_dim % 128 != 0 || embed_dim > 2048 || ((uintptr_t)out_values & 15))
+        return vh_fail(1, "vh_launch_layer_norm_mx: embed_dim=%d must be a multiple of 128, <= 2048, values 16-byte aligned", embed_dim);
+    if (in_row_stride % 4 != 0 || in_row_stride < embed_dim)
+        return vh_fail(1, "vh_launch_layer_norm_mx: row stride must be a multiple of 4 floats and >= embed_dim");
+    const int nv = (embed_dim / 4 + 63) / 64;
+    const size_t lds = (size_t)(embed_dim / 128) * LN3_ROWS * (128 + 4);
+    const dim3 grid((rows + LN3_ROWS - 1) / LN3_ROWS), block(64 * LN3_ROWS);
+    hipStream_t st = (hipStream_t)s;
+#define VH_LNMX(NV)                                                                                           \
+    hipLaunchKernelGGL((layernorm_mx_kernel<NV>), grid, block, lds, st, input, weight, bias,                   \
+                       static_cast<char *>(out_values), static_cast<unsigned char *>(out_scales), rows,      \
+                       embed_dim, in_row_stride, eps)
+    if (nv <= 3) VH_LNMX(3);
+    else if (nv <= 4) VH_LNMX(4);
+    else if (nv <= 5) VH_LNMX(5);
+    else VH_LNMX(8);
+#undef VH_LNMX
+    VH_LAUNCH_CHECK("layernorm_mx_kernel");
+    return 0;
 }
 
 extern "C" int vh_launch_softmax(vh_stream_t s, const float *input, float *output, int rows,

@@ -36,11 +36,11 @@ EXPORTS = [
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_profile_select", "vit_hip_create_ex", "vit_hip_precision",
     "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_launch_split3_planes", "vh_launch_linear_w3",
     "vh_launch_split2h_planes", "vh_launch_linear_h2", "vh_launch_attention_h2", "vh_launch_attention_f16",
-    "vh_launch_convert_fp8", "vh_launch_quantize_rows_fp8", "vh_launch_absmax", "vh_launch_scale_vector",
-    "vh_launch_layer_norm_fp8", "vh_launch_linear_fp8", "vit_hip_calibrate_fp8", "vit_hip_fp8_scales",
+    "vh_launch_absmax",
     "vh_launch_split3_rows", "vh_launch_merge3_rows", "vh_launch_layer_norm_p3", "vh_launch_attention_p3",
     "vh_launch_linear_p3", "vh_launch_split_rows", "vh_launch_merge_rows", "vh_launch_layer_norm_planes",
     "vh_launch_attention_planes_bf16", "vh_launch_linear_planes", "vh_launch_attention_planes",
+    "vh_launch_quantize_mx_rows", "vh_launch_linear_mx", "vh_launch_layer_norm_mx",
     "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
     "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
@@ -164,6 +164,9 @@ def lib() -> C.CDLL:
     L.vh_launch_layer_norm_planes.argtypes = [voidp] + [voidp] * 4 + [i, i, i, C.c_long, C.c_double]
     L.vh_launch_attention_planes_bf16.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_attention_planes.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_quantize_mx_rows.argtypes = [voidp, voidp, voidp, voidp, i, i]
+    L.vh_launch_layer_norm_mx.argtypes = [voidp] + [voidp] * 5 + [i, i, C.c_long, C.c_double]
+    L.vh_launch_linear_mx.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, voidp, voidp, i, i, i, i, voidp]
     L.vh_launch_linear_planes.argtypes = [voidp, voidp, i, voidp, voidp, i, voidp, i, i, i, i, voidp]
     L.vit_config_preset.argtypes = [C.POINTER(VitConfig), C.c_char_p]
     L.vit_config_tokens.argtypes = [C.POINTER(VitConfig)]
@@ -176,14 +179,7 @@ def lib() -> C.CDLL:
     L.vit_hip_create_ex.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i, i]
     L.vit_hip_precision.argtypes = [voidp]
     f = C.c_float
-    L.vh_launch_convert_fp8.argtypes = [voidp, voidp, voidp, sz, f]
-    L.vh_launch_quantize_rows_fp8.argtypes = [voidp, voidp, voidp, voidp, i, i]
     L.vh_launch_absmax.argtypes = [voidp, voidp, sz, voidp]
-    L.vh_launch_scale_vector.argtypes = [voidp, voidp, voidp, f, i]
-    L.vh_launch_layer_norm_fp8.argtypes = [voidp] + [voidp] * 4 + [f, i, i, C.c_long, C.c_long, C.c_double]
-    L.vh_launch_linear_fp8.argtypes = [voidp, voidp, i, voidp, voidp, voidp, voidp, f, i, i, i, i, voidp]
-    L.vit_hip_calibrate_fp8.argtypes = [voidp, voidp, i]
-    L.vit_hip_fp8_scales.argtypes = [voidp, f32p, i]
     L.vit_hip_destroy.argtypes = [voidp]
     L.vit_hip_destroy.restype = None
     L.vh_set_device.argtypes = [i]
@@ -351,21 +347,6 @@ class ViTHip:
         """Device-resident path; pointers are ints / c_void_p / DeviceBuffer.ptr."""
         check(self.L.vit_hip_forward_device(self.ctx, d_images, n, d_logits, d_probs, stream),
               "vit_hip_forward_device")
-
-    def calibrate_fp8(self, images: np.ndarray) -> np.ndarray:
-        """FP8_GEMM contexts: record the GEMM-input ranges over `images` ([n][C][H][W], host);
-        returns the scales [depth][4] (LN1 out, attention out, LN2 out, MLP hidden)."""
-        d = DeviceBuffer.from_numpy(np.ascontiguousarray(images, dtype=np.float32))
-        try:
-            return self.calibrate_fp8_device(d.ptr, images.shape[0])
-        finally:
-            d.free()
-
-    def calibrate_fp8_device(self, d_images, n: int) -> np.ndarray:
-        check(self.L.vit_hip_calibrate_fp8(self.ctx, d_images, n), "vit_hip_calibrate_fp8")
-        out = np.zeros(4 * self.cfg.depth, dtype=np.float32)
-        got = self.L.vit_hip_fp8_scales(self.ctx, fptr(out), out.size)
-        return out[:got].reshape(-1, 4)
 
     def sync(self):
         check(self.L.vh_stream_sync(self.stream), "vh_stream_sync")
