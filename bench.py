@@ -205,13 +205,17 @@ def main() -> None:
         stream = model.stream
     gathered = [None]
 
+    def logits_host():
+        """this rank's [B][NC] logits of the last step, on the host"""
+        return t_logits.cpu().numpy() if use_rccl else d_logits.to_numpy((B, NC))
+
     def step():
         model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
         if use_rccl:
             with torch.cuda.stream(t_stream):
                 gathered[0] = comm.gather_rows(t_logits)
         elif comm is not None:   # gloo rehearsal: through host memory
-            gathered[0] = comm.gather_rows(torch.from_numpy(d_logits.to_numpy((B, NC))))
+            gathered[0] = comm.gather_rows(torch.from_numpy(logits_host()))
 
     def fence():
         if comm is not None:
@@ -268,7 +272,7 @@ def main() -> None:
         pkg.binding.check(L.vh_device_sync(), "sync")
         p2 = m2.profile_read()
         l2 = d_l2.to_numpy((B, NC))
-        l32 = d_logits.to_numpy((B, NC))
+        l32 = logits_host()
         m2.close()
         return ({"dtype": label, "value": round(B / dt2, 1), "unit": "images/sec", "ms_per_step": round(dt2 * 1e3, 3),
                  "max_abs_dlogit_vs_f32_path": float(np.abs(l2 - l32).max()),
@@ -394,7 +398,7 @@ def main() -> None:
             logits0 = gathered[0][0][0].cpu().numpy()
             assert len(gathered[0]) == world and all(t.shape == (B, NC) for t in gathered[0])
         else:
-            logits0 = d_logits.to_numpy((B, NC))[0]
+            logits0 = logits_host()[0]
         probs0 = d_probs.to_numpy((B, NC))[0]
         out = {
             "metric": f"images/sec {label} 224x224 bs{B}" if (args.model, B) != ("vit_b_16", 512) else "images/sec ViT-B/16 224x224 bs512", "value": round(value, 2), "unit": "images/sec",
@@ -427,7 +431,7 @@ def main() -> None:
             base, ref_logits = cpu_baseline(B, args.cpu_procs)
             out["cpu_baseline"] = base
             if ref_logits:
-                gl = d_logits.to_numpy((B, NC))
+                gl = logits_host()
                 imgs = sorted(ref_logits)
                 dl = {i: float(np.abs(gl[i] - ref_logits[i]).max()) for i in imgs}
                 out["parity"] = {"max_abs_dlogit_vs_ViT_seq": max(dl.values()),

@@ -185,15 +185,19 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
     free(ctx);
 }
 
+/* $VIT_HIP_PRECISION: F32 unless asked otherwise: "bf16" -> BF16_GEMM, "fp16x2" -> F32_FP16X2, "fp8" -> FP8_GEMM */
+static int env_precision(void)
+{
+    const char *env = getenv("VIT_HIP_PRECISION");
+    return (env && env[0] == 'b') ? VIT_PRECISION_BF16_GEMM
+         : (env && strncmp(env, "fp16x2", 6) == 0) ? VIT_PRECISION_F32_FP16X2
+         : (env && strncmp(env, "fp8", 3) == 0) ? VIT_PRECISION_FP8_GEMM : VIT_PRECISION_F32;
+}
+
 int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                    int n_tensors, int device, int max_batch)
 {
-    /* F32 unless asked otherwise: "bf16" -> BF16_GEMM, "fp16x2" -> F32_FP16X2, "fp8" -> FP8_GEMM */
-    const char *env = getenv("VIT_HIP_PRECISION");
-    const int precision = (env && env[0] == 'b') ? VIT_PRECISION_BF16_GEMM
-                        : (env && strncmp(env, "fp16x2", 6) == 0) ? VIT_PRECISION_F32_FP16X2
-                        : (env && strncmp(env, "fp8", 3) == 0) ? VIT_PRECISION_FP8_GEMM : VIT_PRECISION_F32;
-    return vit_hip_create_ex(out, cfg, networks, n_tensors, device, max_batch, precision);
+    return vit_hip_create_ex(out, cfg, networks, n_tensors, device, max_batch, env_precision());
 }
 
 int vit_hip_precision(const vit_hip_ctx *ctx) { return ctx->precision; }
@@ -926,9 +930,7 @@ void ViT_opencl(ImageData *image, Network *networks, float **probabilities)
         chunk = atoi(envb) < per_device ? atoi(envb) : per_device;
     if (n_devices > 1) {
         /* $VIT_HIP_DEVICES names several GPUs: contiguous shards of the images, one replica per device */
-        const char *envp = getenv("VIT_HIP_PRECISION");
-        const int precision = (envp && envp[0] == 'b') ? VIT_PRECISION_BF16_GEMM
-                            : (envp && strncmp(envp, "fp16x2", 6) == 0) ? VIT_PRECISION_F32_FP16X2 : VIT_PRECISION_F32;
+        const int precision = env_precision();
         vit_hip_multi *m = NULL;
         int rcm = vit_hip_create_multi(&m, &cfg, networks, vit_config_num_tensors(&cfg), devices, n_devices, chunk, precision);
         if (rcm != 0) {
