@@ -106,7 +106,10 @@ int vit_hip_forward(vit_hip_ctx *ctx, const ImageData *images, int n, float *log
 
 /* Device-resident forward: d_images is [n][C][H][W] fp32 already in HBM,
  * n <= max_batch; d_logits / d_probs ([n][num_classes] device buffers) may each
- * be NULL.  Asynchronous on `stream` (NULL = the context's own stream). */
+ * be NULL.  Asynchronous on `stream`.  A NULL / 0 handle means the CONTEXT'S OWN stream (vit_hip_stream(), created
+ * non-blocking), not HIP's legacy null stream: work a caller has queued on the null stream, or on a framework's
+ * "current stream" whose handle is 0, is NOT ordered against it -- pass a real stream handle to order against
+ * other work on it (bench.py's RCCL gather does). */
 int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float *d_logits,
                            float *d_probs, vh_stream_t stream);
 

@@ -773,7 +773,7 @@ __global__ void split3_planes_kernel(const float *__restrict__ in, __bf16 *__res
 namespace {
 
 /* Pre-split-weight GEMM on the tile the shape wants, with the last, partly filled scheduling round
- * of 256x256 tiles handed to 128x128 tiles instead (VIT_HIP_GEMM_TAIL=0 disables): with one
+ * of 256x256 tiles handed to 128x128 tiles instead: with one
  * workgroup per CU a grid of r.f rounds costs ceil(r.f) rounds; the remainder rows as quarter-size
  * tiles cost about f/2. */
 template <int EPI, int NPL>
