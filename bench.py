@@ -253,9 +253,9 @@ def main() -> None:
 
     # Secondary leg (N=1, default dtype only): the same step with bf16-operand GEMMs, reported
     # beside -- never instead of -- the fp32 `value`.
-    bf16_leg = emu_leg = None
+    bf16_leg = emu_leg = fp8_leg = None
 
-    def secondary(precision, label):
+    def secondary(precision, label, peak_tf, peak_note):
         m2 = pkg.ViTHip(cfg, weights, device=device, max_batch=B, precision=precision)
         d_l2 = pkg.DeviceBuffer(B * NC)
         for _ in range(2):
@@ -274,16 +274,23 @@ def main() -> None:
         l2 = d_l2.to_numpy((B, NC))
         l32 = logits_host()
         m2.close()
+        fc1_ms2 = p2["fc1_gemm"][0] / max(p2["fc1_gemm"][1], 1)
+        fc1_tf = 2.0 * B * tokens * cfg.embed_dim * cfg.mlp_hidden / (fc1_ms2 * 1e-3) / 1e12
         return ({"dtype": label, "value": round(B / dt2, 1), "unit": "images/sec", "ms_per_step": round(dt2 * 1e3, 3),
                  "max_abs_dlogit_vs_f32_path": float(np.abs(l2 - l32).max()),
                  "argmax_agreement_with_f32_path": float((l2.argmax(1) == l32.argmax(1)).mean()),
+                 "roofline": {"bound": "mfma", "kernel": "fc1 GEMM of this mode", "achieved": round(fc1_tf, 1), "peak": peak_tf,
+                              "unit": "TFLOP/s", "frac": round(fc1_tf / peak_tf, 4), "peak_basis": peak_note, "traffic": None},
                  "kernels_avg_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in p2.items() if cnt}}, l2)
 
     emu_logits0 = None
     if comm is None and args.dtype == "f32":
-        bf16_leg, _ = secondary("bf16", "bf16 GEMM operands, fp32 accumulate/residual/attention")
+        bf16_leg, _ = secondary("bf16", "bf16 GEMM operands, fp32 accumulate/residual/attention", 2500.0, "dense bf16 MFMA")
+        fp8_leg, _ = secondary("fp8", "block-scaled e4m3 GEMM operands (OCP MX, 32-element e8m0 scales, no calibration), fp32 "
+                               "accumulate/residual", 5000.0, "dense block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4)")
         emu_leg, emu_l = secondary("f32_fp16x2", "fp32 operands emulated with two fp16 parts and three fp16 MFMAs per "
-                                   "product (22 of 24 significand bits; NOT exact), everything else as the fp32 path")
+                                   "product (22 of 24 significand bits; NOT exact), everything else as the fp32 path",
+                                   2500.0 / 3.0, "dense fp16 MFMA peak / 3: three fp16 MFMAs per emulated product block")
         emu_logits0 = emu_l[0]
         # restore the fp32 path's probabilities for the checks below
         model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
@@ -423,6 +430,7 @@ def main() -> None:
         }
         if bf16_leg is not None:
             out["bf16_gemm_mode"] = bf16_leg
+            out["fp8_block_scaled_gemm_mode"] = fp8_leg
         if emu_leg is not None:
             out["fp32_fp16x2_emulation_mode"] = emu_leg
         if e2e is not None:

@@ -150,7 +150,9 @@ int vh_launch_layer_norm_planes(vh_stream_t s, const float *input, const float *
                                 void *out_planes, int parts, int rows, int embed_dim, long in_row_stride, double eps);
 int vh_launch_attention_planes_bf16(vh_stream_t s, const float *qkv, void *out_planes, int n_images, int tokens,
                                     int embed_dim, int num_heads);   /* one-part planes, arithmetic of vh_launch_attention_f16 */
-/* colA % 64 == 0 (parts 3) or % 128 == 0 (parts 1); fp32 accumulation, bias, GELU, residual as vh_launch_linear */
+/* colA % 64 == 0 (parts 3) or % 128 == 0 (parts 1); fp32 accumulation, bias, GELU, residual as vh_launch_linear.
+ * output_planes: 0 = fp32 rows [rowA][colB]; 1 = planes of `parts` parts (no residual); 2 (parts 1, no GELU, no
+ * residual) = one-part planes of FP16 values [colB/32][rowA][32] -- the Q|K|V input of vh_launch_attention_planes_f16 */
 int vh_launch_linear_planes(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
                             const void *input_planes, int parts, const float *bias, int rowA, int colA, int colB,
                             int doGelu, const float *residual);
@@ -165,6 +167,12 @@ int vh_launch_attention_p3(vh_stream_t s, const float *qkv, void *out_planes, in
  * arithmetic left but that of the probabilities (csrc/attention_p3.hip).  head_dim 64, tokens <= 208. */
 int vh_launch_attention_planes(vh_stream_t s, const void *qkv_planes, void *out_planes, int n_images, int tokens,
                                int embed_dim, int num_heads);
+/* The reduced-precision modes' attention on planes: qkv_planes_f16 [3*embed_dim/32][n_images*tokens][32] fp16 (the QKV
+ * projection with output_planes = 2, or vh_launch_linear_mx_planes_f16); output = one-part bf16 planes
+ * [embed_dim/32][rows][32] (output_planes != 0) or fp32 rows [rows][embed_dim].  Arithmetic of vh_launch_attention_f16
+ * (same results bit for bit on the same fp16 values); head_dim 64, tokens <= 208. */
+int vh_launch_attention_planes_f16(vh_stream_t s, const void *qkv_planes_f16, void *output, int output_planes,
+                                   int n_images, int tokens, int embed_dim, int num_heads);
 /* vh_launch_linear on planes: input_planes [colA/32][3][rowA][32], weight_planes [colA/32][3][colB][32];
  * output fp32 [rowA][colB], or (output_planes != 0, no residual) planes [colB/32][3][rowA][32].
  * colA % 64 == 0, colB % 128 == 0. */
@@ -227,6 +235,13 @@ int vh_launch_layer_norm_mx(vh_stream_t s, const float *input, const float *weig
 int vh_launch_linear_mx(vh_stream_t s, void *output, void *output_scales, const void *weight_values,
                         const void *weight_scales, const void *input_values, const void *input_scales,
                         const float *bias, int rowA, int colA, int colB, int doGelu, const float *residual);
+/* vh_launch_attention_planes_f16 writing an MX tensor (= vh_launch_quantize_mx_rows of its fp32 result, byte for byte) */
+int vh_launch_attention_planes_f16_mx(vh_stream_t s, const void *qkv_planes_f16, void *out_values, void *out_scales,
+                                      int n_images, int tokens, int embed_dim, int num_heads);
+/* the same product (no GELU, no residual) written as one-part fp16 planes [colB/32][rowA][32] */
+int vh_launch_linear_mx_planes_f16(vh_stream_t s, void *output_planes_f16, const void *weight_values,
+                                   const void *weight_scales, const void *input_values, const void *input_scales,
+                                   const float *bias, int rowA, int colA, int colB);
 
 #ifdef __cplusplus
 }

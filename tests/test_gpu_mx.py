@@ -152,3 +152,39 @@ def test_model_fp8_mode_block_scaled(pkg, device, weights, golden_full):
     top2 = np.sort(ref, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 4 * np.abs(logits - ref).max(axis=1)
     assert (logits.argmax(1) == ref.argmax(1))[clear].all()
+
+
+@pytest.mark.parametrize("M,K,N", [(197, 768, 2304), (19700, 768, 2304)])
+def test_linear_mx_fp16_planes_output_is_the_fp32_result_rounded_to_fp16(pkg, device, oracle, M, K, N):
+    """vh_launch_linear_mx_planes_f16 (the fp8 mode's Q|K|V): the fp32 output of vh_launch_linear_mx rounded to
+    nearest-even fp16, as one-part planes [N/32][M][32]."""
+    x = oracle.synth_fill(M * K, 810 + M, 1.0, 0.1).reshape(M, K)
+    w = oracle.synth_fill(N * K, 811 + N, 0.04, 0.0).reshape(N, K)
+    d_b = _dev(pkg, oracle.synth_fill(N, 812, 0.1, 0.0))
+    d_xv, d_xs = _quantize_gpu(pkg, x)
+    d_wv, d_ws = _quantize_gpu(pkg, w)
+    d_o, d_h = pkg.DeviceBuffer(M * N), pkg.DeviceBuffer(M * N // 2 + 1)
+    _launch(pkg, "vh_launch_linear_mx", None, d_o.ptr, None, d_wv.ptr, d_ws.ptr, d_xv.ptr, d_xs.ptr, d_b.ptr, M, K, N, 0, None)
+    _launch(pkg, "vh_launch_linear_mx_planes_f16", None, d_h.ptr, d_wv.ptr, d_ws.ptr, d_xv.ptr, d_xs.ptr, d_b.ptr, M, K, N)
+    got = d_h.to_numpy().view(np.float16)[:M * N].reshape(N // 32, M, 32).astype(np.float32).transpose(1, 0, 2).reshape(M, N)
+    assert np.array_equal(got, d_o.to_numpy((M, N)).astype(np.float16).astype(np.float32))
+
+
+@pytest.mark.parametrize("n_images,tokens", [(1, 197), (3, 197), (2, 5), (40, 33), (2, 1)])
+def test_attention_writing_mx_equals_attention_then_the_row_quantiser(pkg, device, oracle, n_images, tokens):
+    """vh_launch_attention_planes_f16_mx = vh_launch_attention_planes_f16 (fp32 rows) followed by
+    vh_launch_quantize_mx_rows, byte for byte (values and scales)."""
+    E, H = 768, 12
+    rows = n_images * tokens
+    qkv = oracle.synth_fill(rows * 3 * E, 278 + tokens, 1.0, 0.0).reshape(rows, 3 * E)
+    planes = np.ascontiguousarray(qkv.astype(np.float16).reshape(rows, 3 * E // 32, 32).transpose(1, 0, 2))
+    d_qh = pkg.DeviceBuffer.from_numpy(planes.ravel().view(np.float32))
+    d_o = pkg.DeviceBuffer(rows * E)
+    d_v1, d_s1 = pkg.DeviceBuffer(rows * E // 4 + 4), pkg.DeviceBuffer(rows * E // 128 + 4)
+    d_v2, d_s2 = pkg.DeviceBuffer(rows * E // 4 + 4), pkg.DeviceBuffer(rows * E // 128 + 4)
+    _launch(pkg, "vh_launch_attention_planes_f16", None, d_qh.ptr, d_o.ptr, 0, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_quantize_mx_rows", None, d_o.ptr, d_v1.ptr, d_s1.ptr, rows, E)
+    _launch(pkg, "vh_launch_attention_planes_f16_mx", None, d_qh.ptr, d_v2.ptr, d_s2.ptr, n_images, tokens, E, H)
+    assert np.array_equal(_bytes(d_s1, rows * E // 32), _bytes(d_s2, rows * E // 32))
+    assert np.array_equal(_bytes(d_v1, rows * E), _bytes(d_v2, rows * E))
+    assert pkg.lib().vh_launch_attention_planes_f16_mx(None, d_qh.ptr, d_v2.ptr, None, n_images, tokens, E, H) != 0

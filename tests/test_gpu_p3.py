@@ -318,3 +318,62 @@ def test_layer_norm_and_attention_one_part_planes_are_the_rounded_fp32_results(p
     _launch(pkg, "vh_launch_attention_f16", None, d_q.ptr, d_o.ptr, n_images, tokens, E, H)
     _launch(pkg, "vh_launch_attention_planes_bf16", None, d_q.ptr, d_o1.ptr, n_images, tokens, E, H)
     assert np.array_equal(_planes1_to_f32(d_o1, rows, E), _bf16_rne(d_o.to_numpy((rows, E))))
+
+
+def _planes_f16_to_f32(buf, rows, cols):
+    """one-part fp16 planes [cols/32][rows][32] -> float32 [rows][cols]"""
+    raw = buf.to_numpy().view(np.float16)[:rows * cols].reshape(cols // 32, rows, 32)
+    return raw.astype(np.float32).transpose(1, 0, 2).reshape(rows, cols)
+
+
+def _f16_planes_dev(pkg, x):
+    """float32 [rows][cols] -> device buffer of one-part fp16 planes [cols/32][rows][32] (numpy rounds to nearest even)"""
+    rows, cols = x.shape
+    planes = np.ascontiguousarray(x.astype(np.float16).reshape(rows, cols // 32, 32).transpose(1, 0, 2))
+    pad = (-planes.size) % 2
+    raw = np.concatenate([planes.ravel().view(np.uint16), np.zeros(pad, np.uint16)]).view(np.float32)
+    return pkg.DeviceBuffer.from_numpy(raw)
+
+
+@pytest.mark.parametrize("M,K,N", [(197, 768, 2304), (5, 128, 128), (19700, 768, 2304)])
+def test_linear_planes_fp16_output_is_the_fp32_result_rounded_to_fp16(pkg, device, oracle, M, K, N):
+    """output_planes = 2 (the reduced modes' Q|K|V): the values of output_planes = 0 rounded to nearest-even fp16,
+    in one-part plane order -- on small tiles, big tiles and the tail launch."""
+    x = oracle.synth_fill(M * K, 900 + M, 1.0, 0.1).reshape(M, K)
+    w = oracle.synth_fill(N * K, 901 + N, 0.04, 0.0)
+    b = oracle.synth_fill(N, 902, 0.1, 0.0)
+    d_x, d_w, d_b = _dev(pkg, x), _dev(pkg, w), _dev(pkg, b)
+    d_w1, d_x1 = pkg.DeviceBuffer((N * K + 1) // 2), pkg.DeviceBuffer((M * K + 1) // 2)
+    _launch(pkg, "vh_launch_split_rows", None, d_w.ptr, d_w1.ptr, N, K, 1)
+    _launch(pkg, "vh_launch_split_rows", None, d_x.ptr, d_x1.ptr, M, K, 1)
+    d_o, d_h = pkg.DeviceBuffer(M * N), pkg.DeviceBuffer((M * N + 1) // 2)
+    _launch(pkg, "vh_launch_linear_planes", None, d_o.ptr, 0, d_w1.ptr, d_x1.ptr, 1, d_b.ptr, M, K, N, 0, None)
+    _launch(pkg, "vh_launch_linear_planes", None, d_h.ptr, 2, d_w1.ptr, d_x1.ptr, 1, d_b.ptr, M, K, N, 0, None)
+    assert np.array_equal(_planes_f16_to_f32(d_h, M, N), d_o.to_numpy((M, N)).astype(np.float16).astype(np.float32))
+    L = pkg.lib()
+    assert L.vh_launch_linear_planes(None, d_h.ptr, 2, d_w1.ptr, d_x1.ptr, 1, d_b.ptr, M, K, N, 1, None) != 0      # no GELU
+    assert L.vh_launch_linear_planes(None, d_h.ptr, 2, d_w1.ptr, d_x1.ptr, 3, d_b.ptr, M, K, N, 0, None) != 0      # one part only
+    assert L.vh_launch_linear_planes(None, d_h.ptr, 3, d_w1.ptr, d_x1.ptr, 1, d_b.ptr, M, K, N, 0, None) != 0
+
+
+@pytest.mark.parametrize("n_images,tokens", [(1, 197), (3, 197), (2, 5), (1, 208), (40, 33), (300, 64), (2, 1)])
+def test_attention_on_fp16_planes_equals_the_fp16_operand_attention_on_rows_bitwise(pkg, device, oracle, n_images, tokens):
+    """vh_launch_attention_planes_f16 (Q|K|V already rounded to fp16 by the projection, as planes) against
+    vh_launch_attention_f16 / vh_launch_attention_planes_bf16 (fp32 rows in, rounded inside the kernel): the same
+    products in the same order -- fp32 rows out and one-part bf16 planes out, bit for bit."""
+    E, H = 768, 12
+    rows = n_images * tokens
+    qkv = oracle.synth_fill(rows * 3 * E, 178 + tokens, 1.0, 0.0).reshape(rows, 3 * E)
+    d_q, d_qh = _dev(pkg, qkv), _f16_planes_dev(pkg, qkv)
+    d_a, d_b = pkg.DeviceBuffer(rows * E), pkg.DeviceBuffer(rows * E)
+    _launch(pkg, "vh_launch_attention_f16", None, d_q.ptr, d_a.ptr, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_attention_planes_f16", None, d_qh.ptr, d_b.ptr, 0, n_images, tokens, E, H)
+    a, b = d_a.to_numpy((rows, E)), d_b.to_numpy((rows, E))
+    assert np.isfinite(b).all() and np.array_equal(a, b)
+    d_a1, d_b1 = pkg.DeviceBuffer(rows * E // 2 + 1), pkg.DeviceBuffer(rows * E // 2 + 1)
+    _launch(pkg, "vh_launch_attention_planes_bf16", None, d_q.ptr, d_a1.ptr, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_attention_planes_f16", None, d_qh.ptr, d_b1.ptr, 1, n_images, tokens, E, H)
+    assert np.array_equal(_planes1_to_f32(d_a1, rows, E), _planes1_to_f32(d_b1, rows, E))
+    L = pkg.lib()
+    assert L.vh_launch_attention_planes_f16(None, d_qh.ptr, d_b.ptr, 0, n_images, 209, E, H) != 0
+    assert L.vh_launch_attention_planes_f16(None, None, d_b.ptr, 0, n_images, tokens, E, H) != 0

@@ -443,10 +443,17 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         char *ys = (char *)ctx->y + align_up((size_t)rows * E, 256), *as_ = (char *)ctx->attn + align_up((size_t)rows * E, 256);
         char *hs = (char *)ctx->hid + align_up((size_t)rows * F, 256);
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[0], lw[1], ctx->y, ys, rows, E, E, c->eps));
-        OP(VIT_OP_QKV, vh_launch_linear_mx(s, ctx->qkv, NULL, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E, 0, NULL));
-        /* attention on fp16-rounded operands, fp32 out (into the idle MLP buffer), then quantised (one timed operator) */
-        OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                             vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
+        /* attention on fp16-rounded operands.  head_dim 64 / T <= 208: the projection's epilogue rounds Q|K|V to fp16
+         * planes and the attention kernel writes the MX tensor; other shapes: fp32 out (into the idle MLP buffer),
+         * then quantised (one timed operator) */
+        if (E == 64 * c->num_heads && T <= 208) {
+            OP(VIT_OP_QKV, vh_launch_linear_mx_planes_f16(s, ctx->qkv, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E));
+            OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16_mx(s, ctx->qkv, ctx->attn, as_, n, T, E, c->num_heads));
+        } else {
+            OP(VIT_OP_QKV, vh_launch_linear_mx(s, ctx->qkv, NULL, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E, 0, NULL));
+            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                                 vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
+        }
         OP(VIT_OP_OUT_PROJ, vh_launch_linear_mx(s, ctx->x, NULL, l8[4], l8s[4], ctx->attn, as_, lw[5], rows, E, E, 0, ctx->x));
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[6], lw[7], ctx->y, ys, rows, E, E, c->eps));
         OP(VIT_OP_FC1, vh_launch_linear_mx(s, ctx->hid, hs, l8[8], l8s[8], ctx->y, ys, lw[9], rows, E, F, 1, NULL));
@@ -471,12 +478,14 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         float **lw = w + 4 + 12 * l;
         void **lw16 = ctx->w16 + 4 + 12 * l;
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_planes(s, ctx->x, lw[0], lw[1], ctx->y, 1, rows, E, E, c->eps));
-        OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 0, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
-        if (E == 64 * c->num_heads && T <= 208)
-            OP(VIT_OP_ATTENTION, vh_launch_attention_planes_bf16(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-        else   /* shapes of the streaming attention kernel: fp32 output (into the idle MLP buffer), then rounded into planes */
+        if (E == 64 * c->num_heads && T <= 208) {   /* Q|K|V rounded to fp16 planes by the projection's epilogue */
+            OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 2, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
+            OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16(s, ctx->qkv, ctx->attn, 1, n, T, E, c->num_heads));
+        } else {   /* shapes of the streaming attention kernel: fp32 output (into the idle MLP buffer), then rounded into planes */
+            OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 0, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
             OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
                                  vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
+        }
         OP(VIT_OP_OUT_PROJ, vh_launch_linear_planes(s, ctx->x, 0, lw16[4], ctx->attn, 1, lw[5], rows, E, E, 0, ctx->x));
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_planes(s, ctx->x, lw[6], lw[7], ctx->y, 1, rows, E, E, c->eps));
         OP(VIT_OP_FC1, vh_launch_linear_planes(s, ctx->hid, 1, lw16[8], ctx->y, 1, lw[9], rows, E, F, 1, NULL));

@@ -46,18 +46,28 @@ typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int NKT> /* NKT 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT */
+/* NKT 32-wide key/query tiles: 32*(NKT-1) < T <= 32*NKT.
+ * NPL = parts per value of the Q|K|V planes: 3 = the exact bf16 split (six products per block, the fp32 path);
+ * 1 = one fp16 part (operands ROUNDED to fp16 by the QKV projection's epilogue, one product per block: the
+ * reduced-precision GEMM modes, the arithmetic of attention_f32.hip's NPL = 1).
+ * OUTK: 3 = three-part bf16 planes (NPL = 3); 4 = one-part bf16 planes; 0 = fp32 rows [rows][E]; 8 = a block-scaled
+ * fp8 (MX) tensor, values [E/128][rows][128] + scales [E/128][4][rows] in out_scales (NPL = 1). */
+template <int NKT, int NPL, int OUTK>
 __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__restrict__ qkv3, char *__restrict__ out3,
+                                                               unsigned char *__restrict__ out_scales,
                                                                int T, int E, int H, int n_items, int RB)
 {
+    static_assert((NPL == 3 && OUTK == 3) || (NPL == 1 && (OUTK == 4 || OUTK == 0 || OUTK == 8)), "parts / output kind");
+    typedef typename PartT<NPL>::type part_t;           /* bf16x8 (three parts) or half8 (one part) */
+    constexpr int NT = NPL == 3 ? 6 : 1;                 /* products per block */
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int slot = 6 * RB * 64;                        /* [K step 2][part 3][RB rows][64 B] */
+    const int slot = 2 * NPL * RB * 64;                  /* [K step 2][part][RB rows][64 B] */
     char *Kb = smem, *Vb = smem + slot;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int E32 = E >> 5, rb16 = RB >> 4, pieces = 6 * rb16;
+    const int E32 = E >> 5, rb16 = RB >> 4, pieces = 2 * NPL * rb16;
     const size_t prow = (size_t)(n_items / H) * T;       /* rows of the whole activation matrix */
 
     /* LDS-DMA piece p = 16 rows x 64 B of one (K step, part): lane fills physical chunk (lane & 3) of row
@@ -66,28 +76,28 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
         const int b = item / H, h = item - b * H;
         const int ks0 = which * E32 + 2 * h;
         for (int p = wave; p < pieces; p += NKT) {
-            const int gp = p / rb16, rb = p - gp * rb16;                 /* gp = 3 * (K step) + part */
+            const int gp = p / rb16, rb = p - gp * rb16;                 /* gp = NPL * (K step) + part */
             const int r = 16 * rb + (lane >> 2);
             int c = lane & 3;
             if (which == 1)
                 c ^= swz64(lane >> 4);                                   /* (r >> 2) & 3 == (lane >> 4) & 3 */
-            const char *src = qkv3 + ((size_t)(ks0 * 3 + gp) * prow + (size_t)b * T + min(r, T - 1)) * 64 + 16 * c;
+            const char *src = qkv3 + ((size_t)(ks0 * NPL + gp) * prow + (size_t)b * T + min(r, T - 1)) * 64 + 16 * c;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + p * 1024), 16, 0, 0);
         }
     };
 
     /* Q fragments of this lane's query (B operand): d = 16g + 8lh .. +7 of part pl */
     const int q = wave * 32 + lr;
-    bf16x8 qp[HD / 16][3];
+    part_t qp[HD / 16][NPL];
     auto load_q = [&](int item) {
         const int b = item / H, h = item - b * H;
         const size_t row = (size_t)b * T + min(q, T - 1);
 #pragma unroll
         for (int g = 0; g < HD / 16; ++g)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                qp[g][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(
-                                qkv3 + ((size_t)((2 * h + (g >> 1)) * 3 + pl) * prow + row) * 64 + 16 * (2 * (g & 1) + lh)));
+            for (int pl = 0; pl < NPL; ++pl)
+                qp[g][pl] = __builtin_bit_cast(part_t, *reinterpret_cast<const f32x4 *>(
+                                qkv3 + ((size_t)((2 * h + (g >> 1)) * NPL + pl) * prow + row) * 64 + 16 * (2 * (g & 1) + lh)));
     };
 
     /* per-lane LDS offsets.  K fragment of key tile j: row 32j + lr, chunk 2(g & 1) + lh of K step g >> 1;
@@ -121,14 +131,14 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
          * is fetched under the six MFMAs of step f (left alone, the compiler issues every read right before its
          * use and the matrix pipe waits out the LDS latency 28 times per item). */
         f32x16 s[NKT];
-        bf16x8 kp[2][3];
-        auto read_k = [&](bf16x8 (&k3)[3], int f) {
+        part_t kp[2][NPL];
+        auto read_k = [&](part_t (&k3)[NPL], int f) {
             const int j = f / (HD / 16), g = f % (HD / 16);
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {                /* in the order the products need them: part 0, 2, 1 */
-                const int pl = (3 - o) % 3;
-                const char *base = Kb + ((g >> 1) * 3 + pl) * RB * 64;
-                k3[pl] = __builtin_bit_cast(bf16x8, (j < NKT - 1)
+            for (int o = 0; o < NPL; ++o) {              /* in the order the products need them: part 0, 2, 1 */
+                const int pl = (NPL - o) % NPL;
+                const char *base = Kb + ((g >> 1) * NPL + pl) * RB * 64;
+                k3[pl] = __builtin_bit_cast(part_t, (j < NKT - 1)
                     ? *reinterpret_cast<const f32x4 *>(base + kofs[g & 1] + j * 32 * 64)
                     : *reinterpret_cast<const f32x4 *>(base + kofs_last[g & 1]));
             }
@@ -145,14 +155,16 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
             if (f + 1 < NKT * (HD / 16))
                 read_k(kp[(f + 1) & 1], f + 1);
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
-                s[j] = mfma_part(kp[f & 1][term_w<3>(t)], qp[g][term_a<3>(t)], s[j]);
+            for (int t = 0; t < NT; ++t)
+                s[j] = mfma_part(kp[f & 1][term_w<NPL>(t)], qp[g][term_a<NPL>(t)], s[j]);
+            if (NPL == 3) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                for (int r = 0; r < 3; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
 
         __syncthreads();                                 /* V of this item has landed; K buffer and Q registers are free */
@@ -205,18 +217,18 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
         /* step f = (key tile j, 16-key half t, d tile dt); the V fragment of step f + 1 (3 parts x 2 transposed
          * reads) is fetched under the MFMAs of step f.  A half whose keys are all >= T carries P = 0 and is skipped
          * (only the last tile can have one); its prefetch reads a clamped, valid row block. */
-        bf16x8 vq[2][3], pp[3];
-        auto read_v = [&](bf16x8 (&v3)[3], int f) {
+        part_t vq[2][NPL], pp[NPL];
+        auto read_v = [&](part_t (&v3)[NPL], int f) {
             const int j = f >> 2, t = (f >> 1) & 1, dt = f & 1;
             const int r0 = (j == NKT - 1) ? min(32 * j + 16 * t, RB - 16) : 32 * j + 16 * t;
 #pragma unroll
-            for (int o3 = 0; o3 < 3; ++o3) {
-                const int pl = (3 - o3) % 3;
-                const char *vp = Vb + (dt * 3 + pl) * RB * 64 + r0 * 64 + vofs;
+            for (int o3 = 0; o3 < NPL; ++o3) {
+                const int pl = (NPL - o3) % NPL;
+                const char *vp = Vb + (dt * NPL + pl) * RB * 64 + r0 * 64 + vofs;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + 8 * 64));
                 typedef short s16x8 __attribute__((ext_vector_type(8)));
-                v3[pl] = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                v3[pl] = __builtin_bit_cast(part_t, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
             }
         };
         read_v(vq[0], 0);
@@ -230,30 +242,71 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
                             f32x4{s[j][8 * t + 4], s[j][8 * t + 5], s[j][8 * t + 6], s[j][8 * t + 7]}, pp);
             if (!(j == NKT - 1 && 32 * j + 16 * t >= T)) {
 #pragma unroll
-                for (int tt = 0; tt < 6; ++tt)
-                    o[dt] = mfma_part(vq[f & 1][term_w<3>(tt)], pp[term_a<3>(tt)], o[dt]);
+                for (int tt = 0; tt < NT; ++tt)
+                    o[dt] = mfma_part(vq[f & 1][term_w<NPL>(tt)], pp[term_a<NPL>(tt)], o[dt]);
             }
         }
 
-        /* planes [E/32][3][rows][32] of the output projection: K step 2h + dt; a lane holds d = 8g + 4lh .. +3
-         * (8 bytes per part); one half-wave exchange per dword gives each half 16 contiguous bytes */
+        /* Output.  A lane holds d = 32dt + 8g + 4lh .. +3 of its query in o[dt][4g .. 4g+3].
+         * Planes [E/32][parts][rows][32] of the output projection (K step 2h + dt): 8 bytes per part and g; one
+         * half-wave exchange per dword gives each half 16 contiguous bytes.  fp32 rows: 16-byte stores as they are. */
         if (q < T) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int OPL = OUTK == 3 ? 3 : 1;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                u32x2 pg[4][3];
+                if (OUTK == 0) {
+                    float *row = reinterpret_cast<float *>(out3) + ((size_t)b * T + q) * E + h * HD + 32 * dt + 4 * lh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4 *>(row + 8 * g) = f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                    continue;
+                }
+                if (OUTK == 8) {
+                    /* columns 64h + 32dt .. +31 of this query = one scale block, held by the lane pair (lh = 0, 1):
+                     * byte 8g + 4lh + e.  After the exchange the lower lane stores bytes 0..15, the upper 16..31. */
+                    float amax = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        amax = fmaxf(amax, fabsf(o[dt][r]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    unsigned sbyte;
+                    float mult;
+                    mx_block_scale(amax, sbyte, mult);
+                    unsigned x[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        x[g] = pack_fp8x4(f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]} * mult);
+                    const auto r02 = __builtin_amdgcn_permlane32_swap(x[0], x[2], false, false);
+                    const auto r13 = __builtin_amdgcn_permlane32_swap(x[1], x[3], false, false);
+                    const int col = h * HD + 32 * dt, ks = col >> 7, blk = (col >> 5) & 3;
+                    const size_t row = (size_t)b * T + q;
+                    *reinterpret_cast<u32x4 *>(out3 + ((size_t)ks * prow + row) * 128 + 32 * blk + 16 * lh) =
+                        u32x4{r02[0], r02[1], r13[0], r13[1]};
+                    if (lh == 0)
+                        out_scales[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * prow + row] = (unsigned char)sbyte;
+                    continue;
+                }
+                u32x2 pg[4][OPL];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 part[3];
-                    split4(f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]}, part[0], part[1], part[2]);
+                    const f32x4 v4 = f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                    if (OUTK == 3) {
+                        split4(v4, part[0], part[1], part[2]);
+                    } else {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                        for (int e = 0; e < 4; ++e)
+                            part[0][e] = (__bf16)v4[e];
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < OPL; ++pl)
                         pg[g][pl] = __builtin_bit_cast(u32x2, part[pl]);
                 }
-                char *d3 = out3 + ((size_t)(2 * h + dt) * 3 * prow + (size_t)b * T + q) * 64 + 16 * lh;
+                char *d3 = out3 + ((size_t)(2 * h + dt) * OPL * prow + (size_t)b * T + q) * 64 + 16 * lh;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < OPL; ++pl)
 #pragma unroll
                     for (int g = 0; g < 4; g += 2) {
                         const auto r0 = __builtin_amdgcn_permlane32_swap(pg[g][pl][0], pg[g + 1][pl][0], false, false);
@@ -267,17 +320,43 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
     }
 }
 
-template <int NKT>
-int launch_k(hipStream_t st, const char *qkv3, char *out3, int n_images, int T, int E, int H)
+template <int NKT, int NPL, int OUTK>
+int launch_k(hipStream_t st, const char *qkv3, char *out3, unsigned char *out_scales, int n_images, int T, int E, int H)
 {
     const int RB = (T + 15) / 16 * 16;
-    const size_t lds = (size_t)2 * 6 * RB * 64;
-    VH_SET_LDS_ONCE((attention_p3_kernel<NKT>), MAX_LDS);
+    const size_t lds = (size_t)2 * 2 * NPL * RB * 64;
+    VH_SET_LDS_ONCE((attention_p3_kernel<NKT, NPL, OUTK>), MAX_LDS);
     const int num_cus = vh_device_cus(vh_current_device());
     const int n_items = n_images * H;
     const int grid = n_items < num_cus ? n_items : num_cus;
-    hipLaunchKernelGGL((attention_p3_kernel<NKT>), dim3(grid), dim3(64 * NKT), lds, st, qkv3, out3, T, E, H, n_items, RB);
+    hipLaunchKernelGGL((attention_p3_kernel<NKT, NPL, OUTK>), dim3(grid), dim3(64 * NKT), lds, st, qkv3, out3, out_scales, T, E, H, n_items, RB);
     VH_LAUNCH_CHECK("attention_p3_kernel");
+    return 0;
+}
+
+template <int NPL, int OUTK>
+int launch_t(hipStream_t st, const char *in, char *out, unsigned char *out_scales, int n_images, int tokens, int embed_dim, int num_heads)
+{
+    switch ((tokens + 31) / 32) {
+    case 1: return launch_k<1, NPL, OUTK>(st, in, out, out_scales, n_images, tokens, embed_dim, num_heads);
+    case 2: return launch_k<2, NPL, OUTK>(st, in, out, out_scales, n_images, tokens, embed_dim, num_heads);
+    case 3: return launch_k<3, NPL, OUTK>(st, in, out, out_scales, n_images, tokens, embed_dim, num_heads);
+    case 4: return launch_k<4, NPL, OUTK>(st, in, out, out_scales, n_images, tokens, embed_dim, num_heads);
+    case 5: return launch_k<5, NPL, OUTK>(st, in, out, out_scales, n_images, tokens, embed_dim, num_heads);
+    case 6: return launch_k<6, NPL, OUTK>(st, in, out, out_scales, n_images, tokens, embed_dim, num_heads);
+    default: return launch_k<7, NPL, OUTK>(st, in, out, out_scales, n_images, tokens, embed_dim, num_heads);
+    }
+}
+
+int check_args(const char *who, const void *in, const void *out, int n_images, int tokens, int embed_dim, int num_heads)
+{
+    if (!in || !out)
+        return vh_fail(1, "%s: null pointer argument", who);
+    if (n_images <= 0 || tokens <= 0 || num_heads <= 0 || embed_dim != num_heads * HD || tokens > MAX_ROWS)
+        return vh_fail(1, "%s: needs head_dim 64 and 1 <= tokens <= %d (n=%d tokens=%d embed=%d heads=%d)", who,
+                       MAX_ROWS, n_images, tokens, embed_dim, num_heads);
+    if ((((uintptr_t)in | (uintptr_t)out) & 15) != 0)
+        return vh_fail(1, "%s: pointers must be 16-byte aligned", who);
     return 0;
 }
 
@@ -288,23 +367,37 @@ int launch_k(hipStream_t st, const char *qkv3, char *out3, int n_images, int T, 
 extern "C" int vh_launch_attention_planes(vh_stream_t s, const void *qkv_planes, void *out_planes, int n_images,
                                           int tokens, int embed_dim, int num_heads)
 {
-    if (!qkv_planes || !out_planes)
-        return vh_fail(1, "vh_launch_attention_planes: null pointer argument");
-    if (n_images <= 0 || tokens <= 0 || num_heads <= 0 || embed_dim != num_heads * HD || tokens > MAX_ROWS)
-        return vh_fail(1, "vh_launch_attention_planes: needs head_dim 64 and 1 <= tokens <= %d (n=%d tokens=%d embed=%d heads=%d)",
-                       MAX_ROWS, n_images, tokens, embed_dim, num_heads);
-    if ((((uintptr_t)qkv_planes | (uintptr_t)out_planes) & 15) != 0)
-        return vh_fail(1, "vh_launch_attention_planes: pointers must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)s;
-    const char *in = static_cast<const char *>(qkv_planes);
-    char *out = static_cast<char *>(out_planes);
-    switch ((tokens + 31) / 32) {
-    case 1: return launch_k<1>(st, in, out, n_images, tokens, embed_dim, num_heads);
-    case 2: return launch_k<2>(st, in, out, n_images, tokens, embed_dim, num_heads);
-    case 3: return launch_k<3>(st, in, out, n_images, tokens, embed_dim, num_heads);
-    case 4: return launch_k<4>(st, in, out, n_images, tokens, embed_dim, num_heads);
-    case 5: return launch_k<5>(st, in, out, n_images, tokens, embed_dim, num_heads);
-    case 6: return launch_k<6>(st, in, out, n_images, tokens, embed_dim, num_heads);
-    default: return launch_k<7>(st, in, out, n_images, tokens, embed_dim, num_heads);
-    }
+    if (int rc = check_args("vh_launch_attention_planes", qkv_planes, out_planes, n_images, tokens, embed_dim, num_heads))
+        return rc;
+    return launch_t<3, 3>((hipStream_t)s, static_cast<const char *>(qkv_planes), static_cast<char *>(out_planes), nullptr,
+                          n_images, tokens, embed_dim, num_heads);
+}
+
+/* The reduced-precision GEMM modes: qkv_planes_f16 [3E/32][n_images*tokens][32] fp16 (vh_launch_linear_planes /
+ * vh_launch_linear_mx with output_planes = 2) -> output: one-part bf16 planes [E/32][rows][32] (output_planes = 1, the
+ * next GEMM's operand in the bf16 mode) or fp32 rows [rows][embed_dim] (output_planes = 0).  Arithmetic of
+ * vh_launch_attention_f16: Q, K, V and the probabilities rounded to fp16, fp32 accumulation and softmax. */
+extern "C" int vh_launch_attention_planes_f16(vh_stream_t s, const void *qkv_planes_f16, void *output, int output_planes,
+                                              int n_images, int tokens, int embed_dim, int num_heads)
+{
+    if (int rc = check_args("vh_launch_attention_planes_f16", qkv_planes_f16, output, n_images, tokens, embed_dim, num_heads))
+        return rc;
+    const char *in = static_cast<const char *>(qkv_planes_f16);
+    char *out = static_cast<char *>(output);
+    return output_planes ? launch_t<1, 4>((hipStream_t)s, in, out, nullptr, n_images, tokens, embed_dim, num_heads)
+                         : launch_t<1, 0>((hipStream_t)s, in, out, nullptr, n_images, tokens, embed_dim, num_heads);
+}
+
+/* The same attention writing the output projection's operand of the block-scaled fp8 mode directly: an MX tensor
+ * (values [embed_dim/128][rows][128], scales [embed_dim/128][4][rows]; vh_launch_quantize_mx_rows of the fp32 result,
+ * byte for byte).  embed_dim % 128 == 0. */
+extern "C" int vh_launch_attention_planes_f16_mx(vh_stream_t s, const void *qkv_planes_f16, void *out_values, void *out_scales,
+                                                 int n_images, int tokens, int embed_dim, int num_heads)
+{
+    if (int rc = check_args("vh_launch_attention_planes_f16_mx", qkv_planes_f16, out_values, n_images, tokens, embed_dim, num_heads))
+        return rc;
+    if (!out_scales || embed_dim % 128 != 0)
+        return vh_fail(1, "vh_launch_attention_planes_f16_mx: needs out_scales and embed_dim %% 128 == 0");
+    return launch_t<1, 8>((hipStream_t)s, static_cast<const char *>(qkv_planes_f16), static_cast<char *>(out_values),
+                          static_cast<unsigned char *>(out_scales), n_images, tokens, embed_dim, num_heads);
 }

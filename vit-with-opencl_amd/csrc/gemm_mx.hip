@@ -45,7 +45,7 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2 };
-enum { OUT_F32 = 0, OUT_MX = 1 };
+enum { OUT_F32 = 0, OUT_MX = 1, OUT_PLANES_H = 2 };   /* _H: one-part fp16 planes [N/32][rows][32] (Q|K|V for attention_p3.hip) */
 
 struct MxParams {
     const char *A, *As;       /* activation values [K/128][a_rows][128], scales [K/128][4][a_rows] */
@@ -54,20 +54,6 @@ struct MxParams {
     void *C, *Cs;             /* fp32 [a_rows][N]; or MX values [N/128][a_rows][128] + scales [N/128][4][a_rows] */
     int row_begin, row_end, N, K, a_rows, mtiles, ntiles;
 };
-
-/* scale byte and multiplier of one 32-element block from its largest magnitude: the smallest power of two
- * that brings the block inside e4m3's range, 2^E with E = ceil(log2(amax / 448)).  (OCP MX v1.0 suggests
- * floor(log2(amax)) - 8, which lets maxima with a significand above 1.75 saturate at 448 -- a 12.5 % clip of the
- * block's largest element; rounding the exponent up instead costs at most one bit of the smallest ones.)  Zero /
- * subnormal maxima take the smallest scale the multiplier can undo. */
-__device__ __forceinline__ void mx_block_scale(float amax, unsigned &scale_byte, float &mult)
-{
-    const unsigned bits = __builtin_bit_cast(unsigned, amax);
-    int e = (int)((bits >> 23) & 0xff) - 127 - 8 + ((bits & 0x7fffff) > 0x600000 ? 1 : 0);   /* significand > 1.75 */
-    e = e < -126 ? -126 : e;
-    scale_byte = (unsigned)(e + 127);
-    mult = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);                    /* 2^-e, exact */
-}
 
 template <int NW, int BN, int EPI, int OUTK>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
@@ -253,6 +239,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
                     if (j4 == 0)   /* scales[ks][lane group of block blk][row]: block b is read by lane group 2 (b & 1) + (b >> 1) */
                         static_cast<unsigned char *>(p.Cs)[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * p.a_rows + row] = (unsigned char)sbyte;
                 }
+            } else if (OUTK == OUT_PLANES_H) {
+                if (live) {
+                    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+                    half8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        hv[e] = (_Float16)(e < 4 ? lo[e] : hi[e - 4]);
+                    *reinterpret_cast<f32x4 *>(static_cast<char *>(p.C) + ((size_t)(col >> 5) * p.a_rows + row) * 64 + 16 * j4) =
+                        __builtin_bit_cast(f32x4, hv);
+                }
             } else if (live) {
                 float *cp = static_cast<float *>(p.C) + (size_t)row * p.N + col;
                 *reinterpret_cast<f32x4 *>(cp) = lo;
@@ -364,5 +360,18 @@ extern "C" int vh_launch_linear_mx(vh_stream_t s, void *output, void *output_sca
         return output_scales ? launch_mx<EPI_GELU, OUT_MX>(st, p, small_only) : launch_mx<EPI_GELU, OUT_F32>(st, p, small_only);
     if (residual)
         return launch_mx<EPI_RESID, OUT_F32>(st, p, small_only);
+    if (output_scales == output)   /* see vh_launch_linear_mx_planes_f16 */
+        return launch_mx<EPI_NONE, OUT_PLANES_H>(st, p, small_only);
     return output_scales ? launch_mx<EPI_NONE, OUT_MX>(st, p, small_only) : launch_mx<EPI_NONE, OUT_F32>(st, p, small_only);
+}
+
+/* The same product written as one-part fp16 planes [colB/32][rowA][32] (no GELU, no residual): the Q|K|V input of
+ * vh_launch_attention_planes_f16. */
+extern "C" int vh_launch_linear_mx_planes_f16(vh_stream_t s, void *output_planes_f16, const void *weight_values,
+                                              const void *weight_scales, const void *input_values, const void *input_scales,
+                                              const float *bias, int rowA, int colA, int colB)
+{
+    /* internal convention: output_scales == output selects the fp16-planes epilogue */
+    return vh_launch_linear_mx(s, output_planes_f16, output_planes_f16, weight_values, weight_scales, input_values, input_scales,
+                               bias, rowA, colA, colB, 0, nullptr);
 }

@@ -58,7 +58,7 @@ typedef const __attribute__((address_space(1))) f32x4 *gvec_t;
 #define P1_KG 2   /* one-part operands: 32-deep K groups per LDS stage (one barrier per 32 * P1_KG k) */
 #endif
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2 };
-enum { OUT_F32 = 0, OUT_PLANES = 1 };
+enum { OUT_F32 = 0, OUT_PLANES = 1, OUT_PLANES_H = 2 };   /* _H: one-part planes of fp16 (the reduced modes' Q|K|V) */
 
 struct P3Params {
     const char *A;            /* activation planes [K/32][NPL][a_rows][32] bf16 */
@@ -251,10 +251,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
             }
             if (LAB & 64) {   /* keep the values alive, store nothing */
                 asm volatile("" ::"v"(lo), "v"(hi));
-            } else if (OUTK == OUT_PLANES) {
+            } else if (OUTK == OUT_PLANES || OUTK == OUT_PLANES_H) {
                 frag_t part[3];
                 if (NPL == 3) {
                     split8(lo, hi, part[0], part[1], part[2]);
+                } else if (OUTK == OUT_PLANES_H) {
+                    half8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        hv[e] = (_Float16)(e < 4 ? lo[e] : hi[e - 4]);
+                    part[0] = __builtin_bit_cast(frag_t, hv);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -416,7 +422,8 @@ extern "C" int vh_launch_linear_planes(vh_stream_t s, void *output, int output_p
     const int kstep = parts == 3 ? 64 : 64 * P1_KG;   /* two LDS stages per loop iteration */
     if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % kstep != 0 || colB % 128 != 0)
         return vh_fail(1, "vh_launch_linear_planes: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", kstep, rowA, colA, colB);
-    if ((doGelu && residual) || (residual && output_planes))
+    if ((doGelu && residual) || (residual && output_planes) || output_planes < 0 || output_planes > 2 ||
+        (output_planes == 2 && (parts != 1 || doGelu)))
         return vh_fail(1, "vh_launch_linear_planes: unsupported epilogue combination");
     if ((((uintptr_t)output | (uintptr_t)weight_planes | (uintptr_t)input_planes | (uintptr_t)bias | (uintptr_t)residual) & 15) != 0)
         return vh_fail(1, "vh_launch_linear_planes: pointers must be 16-byte aligned");
@@ -442,6 +449,8 @@ extern "C" int vh_launch_linear_planes(vh_stream_t s, void *output, int output_p
     } while (0)
     if (parts == 3)
         VH_P3_DISPATCH(3);
+    if (output_planes == 2)
+        return launch_p3<EPI_NONE, OUT_PLANES_H, 1>(st, p, small_only);
     VH_P3_DISPATCH(1);
 #undef VH_P3_DISPATCH
 }

@@ -210,14 +210,13 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float
                 amax = fmaxf(amax, __shfl_xor(amax, 1));
                 amax = fmaxf(amax, __shfl_xor(amax, 2));
                 amax = fmaxf(amax, __shfl_xor(amax, 4));
-                const unsigned abits = __builtin_bit_cast(unsigned, amax);   /* as mx_block_scale (gemm_mx.hip) */
-                int ex = (int)((abits >> 23) & 0xff) - 127 - 8 + ((abits & 0x7fffff) > 0x600000 ? 1 : 0);
-                ex = ex < -126 ? -126 : ex;
-                const float mult = __builtin_bit_cast(float, (unsigned)(127 - ex) << 23);
+                unsigned sbyte;
+                float mult;
+                mx_block_scale(amax, sbyte, mult);
                 const int k = 4 * idx, ks = k >> 7, blk = (k >> 5) & 3;
                 *reinterpret_cast<unsigned *>(ln_lds + (ks * LN3_ROWS + wave) * 128 + (k & 127)) = pack_fp8x4(y * mult);
                 if ((lane & 7) == 0)
-                    lds_scales[(ks * 4 + 2 * (blk & 1) + (blk >> 1)) * LN3_ROWS + wave] = (char)(ex + 127);
+                    lds_scales[(ks * 4 + 2 * (blk & 1) + (blk >> 1)) * LN3_ROWS + wave] = (char)sbyte;
             }
         }
     }

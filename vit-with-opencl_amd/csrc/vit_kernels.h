@@ -23,6 +23,20 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v)
     return (unsigned)r;
 }
 
+/* scale byte and multiplier of one 32-element block from its largest magnitude: the smallest power of two
+ * that brings the block inside e4m3's range, 2^E with E = ceil(log2(amax / 448)).  (OCP MX v1.0 suggests
+ * floor(log2(amax)) - 8, which lets maxima with a significand above 1.75 saturate at 448 -- a 12.5 % clip of the
+ * block's largest element; rounding the exponent up instead costs at most one bit of the smallest ones.)  Zero /
+ * subnormal maxima take the smallest scale the multiplier can undo. */
+__device__ __forceinline__ void mx_block_scale(float amax, unsigned &scale_byte, float &mult)
+{
+    const unsigned bits = __builtin_bit_cast(unsigned, amax);
+    int e = (int)((bits >> 23) & 0xff) - 127 - 8 + ((bits & 0x7fffff) > 0x600000 ? 1 : 0);   /* significand > 1.75 */
+    e = e < -126 ? -126 : e;
+    scale_byte = (unsigned)(e + 127);
+    mult = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);                    /* 2^-e, exact */
+}
+
 /* Records `msg` as the calling thread's last error and returns `code`. */
 int vh_fail(int code, const char *fmt, ...);
 /* Converts a hipError_t into the launcher return convention, recording text. */

@@ -41,6 +41,7 @@ EXPORTS = [
     "vh_launch_linear_p3", "vh_launch_split_rows", "vh_launch_merge_rows", "vh_launch_layer_norm_planes",
     "vh_launch_attention_planes_bf16", "vh_launch_linear_planes", "vh_launch_attention_planes",
     "vh_launch_quantize_mx_rows", "vh_launch_linear_mx", "vh_launch_layer_norm_mx",
+    "vh_launch_attention_planes_f16", "vh_launch_linear_mx_planes_f16", "vh_launch_attention_planes_f16_mx",
     "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
     "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
@@ -164,6 +165,9 @@ def lib() -> C.CDLL:
     L.vh_launch_layer_norm_planes.argtypes = [voidp] + [voidp] * 4 + [i, i, i, C.c_long, C.c_double]
     L.vh_launch_attention_planes_bf16.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_attention_planes.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_attention_planes_f16.argtypes = [voidp, voidp, voidp, i, i, i, i, i]
+    L.vh_launch_attention_planes_f16_mx.argtypes = [voidp, voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_linear_mx_planes_f16.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, voidp, i, i, i]
     L.vh_launch_quantize_mx_rows.argtypes = [voidp, voidp, voidp, voidp, i, i]
     L.vh_launch_layer_norm_mx.argtypes = [voidp] + [voidp] * 5 + [i, i, C.c_long, C.c_double]
     L.vh_launch_linear_mx.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, voidp, voidp, i, i, i, i, voidp]
