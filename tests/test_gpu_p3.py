@@ -8,6 +8,7 @@ against the CPU oracle (ViT_seq.c:295-309) on rows that straddle tile and launch
 and the whole model bit for bit against the in-loop-split path.
 """
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -377,3 +378,4 @@ def test_attention_on_fp16_planes_equals_the_fp16_operand_attention_on_rows_bitw
     L = pkg.lib()
     assert L.vh_launch_attention_planes_f16(None, d_qh.ptr, d_b.ptr, 0, n_images, 209, E, H) != 0
     assert L.vh_launch_attention_planes_f16(None, None, d_b.ptr, 0, n_images, tokens, E, H) != 0
+

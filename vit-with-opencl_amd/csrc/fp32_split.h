@@ -73,11 +73,19 @@ __device__ __forceinline__ void split_parts(const f32x4 &u, const f32x4 &v, half
         o[1][e] = (_Float16)(x - (float)h);
     }
 }
+/* The value is made opaque before the conversion: where the fp32 value is itself a product (a probability =
+ * exponential x reciprocal sum) the compiler otherwise fuses multiplication and conversion into one v_fma_mix
+ * with a single rounding -- for some elements of some kernels and not for others, depending on where the
+ * multiplication happens to sit.  Rounded twice (to fp32, then to fp16) everywhere, the attention kernels on rows
+ * and on planes, in step or staggered, agree bit for bit. */
 __device__ __forceinline__ void split_parts(const f32x4 &u, const f32x4 &v, half8 (&o)[1])
 {
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-        o[0][e] = (_Float16)(e < 4 ? u[e] : v[e - 4]);
+    for (int e = 0; e < 8; ++e) {
+        float x = e < 4 ? u[e] : v[e - 4];
+        asm("" : "+v"(x));
+        o[0][e] = (_Float16)x;
+    }
 }
 __device__ __forceinline__ f32x4 mfma_part(bf16x8 w, bf16x8 a, f32x4 c)
 {
