@@ -283,6 +283,28 @@ def main() -> None:
                               "unit": "TFLOP/s", "frac": round(fc1_tf / peak_tf, 4), "peak_basis": peak_note, "traffic": None},
                  "kernels_avg_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in p2.items() if cnt}}, l2)
 
+    # Opt-in leg (never `value`): the last encoder layer's output projection and MLP evaluated for the class-token
+    # rows only -- the rows the classifier reads; logits identical bit for bit (checked here).
+    cls_leg = None
+    if comm is None and args.dtype == "f32":
+        l_full = logits_host()
+        if model.set_last_layer_cls_only(True) is False:
+            for _ in range(2):
+                model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
+            pkg.binding.check(L.vh_device_sync(), "sync")
+            t2 = time.perf_counter()
+            for _ in range(5):
+                model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
+            pkg.binding.check(L.vh_device_sync(), "sync")
+            dt2 = (time.perf_counter() - t2) / 5
+            cls_leg = {"what": "vit_hip_set_last_layer_cls_only(1): last layer's out-proj + LayerNorm + MLP on the "
+                               "class-token rows only (the rows the classifier reads, ViT_seq.c:511); opt-in, default off",
+                       "value": round(B / dt2, 1), "unit": "images/sec", "ms_per_step": round(dt2 * 1e3, 3),
+                       "logits_bit_identical_to_full_evaluation": bool(np.array_equal(logits_host(), l_full))}
+        model.set_last_layer_cls_only(False)
+        model.forward_device(d_images.ptr, B, d_logits_ptr, d_probs.ptr, stream)
+        pkg.binding.check(L.vh_device_sync(), "sync")
+
     emu_logits0 = None
     if comm is None and args.dtype == "f32":
         bf16_leg, _ = secondary("bf16", "bf16 GEMM operands, fp32 accumulate/residual/attention", 2500.0, "dense bf16 MFMA")
@@ -433,6 +455,8 @@ def main() -> None:
             out["fp8_block_scaled_gemm_mode"] = fp8_leg
         if emu_leg is not None:
             out["fp32_fp16x2_emulation_mode"] = emu_leg
+        if cls_leg is not None:
+            out["class_token_rows_only_last_layer"] = cls_leg
         if e2e is not None:
             out["end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline and args.model == "vit_b_16":

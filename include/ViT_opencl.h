@@ -140,6 +140,13 @@ vh_stream_t vit_hip_stream(const vit_hip_ctx *ctx);
 int vit_hip_max_batch(const vit_hip_ctx *ctx);
 /* Device pointer of weight tensor idx (same index map as `networks`). */
 const float *vit_hip_weight(const vit_hip_ctx *ctx, int idx);
+/* Opt-in (default off; $VIT_HIP_LAST_LAYER=cls turns it on at creation): evaluate the last encoder layer's output
+ * projection, LayerNorm and MLP for the class-token rows only -- the only rows the classifier reads (ViT_seq.c:511).
+ * Logits and probabilities are identical bit for bit; the last layer then does not update the other rows of the
+ * residual stream (vit_hip_read_tokens).  fp32 path on planes only (ignored elsewhere).  Returns the previous setting,
+ * -1 for a NULL context. */
+int vit_hip_set_last_layer_cls_only(vit_hip_ctx *ctx, int on);
+
 /* Copy the residual stream left by the last forward ([n*tokens][embed]) to the host. */
 int vit_hip_read_tokens(vit_hip_ctx *ctx, int n, float *host_out);
 

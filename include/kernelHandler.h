@@ -203,6 +203,12 @@ int vh_launch_attention_h2(vh_stream_t s, const float *qkv, float *output, int n
 int vh_launch_attention(vh_stream_t s, const float *qkv, float *output, int n_images,
                         int tokens, int embed_dim, int num_heads);
 
+/* Every row_stride-th row compacted: dst[p][i][:] = src[p][i * row_stride][:] over n_planes planes of src_rows rows of
+ * row_bytes bytes (a row-major fp32 matrix: n_planes 1, row_bytes 4 * cols; a planes tensor: row_bytes 64).  Used to
+ * pull out the class-token rows (ViT_seq.c:511 reads row 0 of every image only).  No reference counterpart. */
+int vh_launch_gather_rows(vh_stream_t s, const void *src, void *dst, int n_planes, int src_rows, int dst_rows,
+                          int row_bytes, int row_stride);
+
 /* Row softmax with max subtraction: output[r][i] = exp(x-max)/sum.  Replaces
  * Softmax (ViT_opencl.c:750-779; softMax miniSoftMax.cl:1); CPU Softmax_seq
  * ViT_seq.c:372. */

@@ -379,3 +379,37 @@ def test_attention_on_fp16_planes_equals_the_fp16_operand_attention_on_rows_bitw
     assert L.vh_launch_attention_planes_f16(None, d_qh.ptr, d_b.ptr, 0, n_images, 209, E, H) != 0
     assert L.vh_launch_attention_planes_f16(None, None, d_b.ptr, 0, n_images, tokens, E, H) != 0
 
+
+
+def test_gather_rows_picks_every_nth_row_of_matrices_and_planes(pkg, device, oracle):
+    rows, cols, stride = 985, 768, 197
+    x = oracle.synth_fill(rows * cols, 41, 1.0, 0.0).reshape(rows, cols)
+    d_x, d_o = _dev(pkg, x), pkg.DeviceBuffer(5 * cols)
+    _launch(pkg, "vh_launch_gather_rows", None, d_x.ptr, d_o.ptr, 1, rows, 5, 4 * cols, stride)
+    assert np.array_equal(d_o.to_numpy((5, cols)), x[::stride])
+    d_p, d_g = _planes_buf(pkg, rows, cols), _planes_buf(pkg, 5, cols)
+    _launch(pkg, "vh_launch_split3_rows", None, d_x.ptr, d_p.ptr, rows, cols)
+    _launch(pkg, "vh_launch_gather_rows", None, d_p.ptr, d_g.ptr, 3 * (cols // 32), rows, 5, 64, stride)
+    assert np.array_equal(_planes_to_parts(d_g, 5, cols), _planes_to_parts(d_p, rows, cols)[:, ::stride])
+    L = pkg.lib()
+    assert L.vh_launch_gather_rows(None, d_x.ptr, d_o.ptr, 1, rows, 6, 4 * cols, stride) != 0       # row 985 does not exist
+    assert L.vh_launch_gather_rows(None, d_x.ptr, d_o.ptr, 1, rows, 5, 4 * cols + 4, stride) != 0
+
+
+def test_last_layer_on_class_token_rows_only_gives_identical_logits(pkg, device, weights, golden_full):
+    """vit_hip_set_last_layer_cls_only: the last layer's output projection, LayerNorm and MLP evaluated for the rows
+    the classifier reads.  Same kernels, same k order: logits and probabilities bit for bit those of the full
+    evaluation (and within 1e-4 of ViT_seq.c's), for one image and for a batch that spans several tiles."""
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 0, 40)
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=40)
+    full_l, full_p = m.forward(imgs)
+    assert m.set_last_layer_cls_only(True) is False
+    cls_l, cls_p = m.forward(imgs)
+    one_l, _ = m.forward(imgs[3:4])
+    assert m.set_last_layer_cls_only(False) is True
+    again_l, _ = m.forward(imgs)
+    m.close()
+    assert np.array_equal(cls_l, full_l) and np.array_equal(cls_p, full_p) and np.array_equal(again_l, full_l)
+    assert np.array_equal(one_l[0], full_l[3])
+    assert np.abs(full_l[:4] - golden_full["logits"][:4]).max() <= 1e-4

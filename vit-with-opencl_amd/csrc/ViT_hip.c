@@ -55,6 +55,7 @@ struct vit_hip_ctx
     void **w3;          /* per tensor index (NULL: use the fp32 tensor) */
     float *w3_scale;    /* F32_FP16X2: per tensor index, the power of two its fp16 parts were scaled by */
     int use_p3;         /* F32: GEMM inputs travel as three-part bf16 planes (y, attn, hid hold 6 bytes per value) */
+    int cls_only_last;  /* use_p3: the last layer's output projection and MLP run on the class-token rows only */
     /* FP8_GEMM: block-scaled e4m3 copies of the same four matrices (values, then their e8m0 block scales) */
     void *w8_slab;
     void **w8, **w8s;   /* per tensor index: values, scales */
@@ -385,6 +386,10 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
         ctx->use_p3 = ctx->w3_slab && precision == VIT_PRECISION_F32 && !(env_p3 && env_p3[0] == '0') &&
                       !(env_native && env_native[0] == 'n') && rows * 64 <= 0xffffffffull;
     }
+    {
+        const char *env_ll = getenv("VIT_HIP_LAST_LAYER");
+        ctx->cls_only_last = ctx->use_p3 && env_ll && strcmp(env_ll, "cls") == 0;
+    }
     const size_t act = ctx->use_p3 ? 6 : sizeof(float);   /* bytes per GEMM-input value */
     TRY(vh_malloc((void **)&ctx->x, rows * E * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->y, rows * E * act));
@@ -435,6 +440,8 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
                                                     c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
 
     const int mode = ctx->precision;
+    const float *final_x = ctx->x;          /* what the final LayerNorm reads: row i * final_stride is image i's class token */
+    long final_stride = (long)T * E;
     for (int l = 0; l < c->depth && mode == VIT_PRECISION_FP8_GEMM; ++l) {
         /* block-scaled fp8 GEMM operands: y, attn and hid hold MX tensors (values, then the scales, in the same
          * allocations); qkv and the residual stream stay fp32; attention as in the other reduced modes */
@@ -505,6 +512,27 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
             OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
                                  vh_launch_split3_rows(s, ctx->hid, ctx->attn, rows, E));
         }
+        if (l == c->depth - 1 && ctx->cls_only_last && T >= 4) {
+            /* Opt-in (vit_hip_set_last_layer_cls_only / $VIT_HIP_LAST_LAYER=cls).  The classifier reads row 0 of every
+             * image only (ViT_seq.c:511), and behind the last attention no operator mixes rows: the output projection,
+             * LayerNorm and MLP of the last layer are evaluated for the n class-token rows instead of n * T, in the
+             * Q|K|V buffer the attention has just released.  Same kernels, same k order: identical logits, bit for
+             * bit; the residual stream of the other rows (vit_hip_read_tokens) is NOT updated by this layer. */
+            char *scratch = (char *)ctx->qkv;
+            float *x_cls = (float *)scratch;
+            char *attn_cls = scratch + align_up((size_t)n * E * 4, 256);
+            char *y_cls = attn_cls + align_up((size_t)n * E * 6, 256);
+            char *hid_cls = y_cls + align_up((size_t)n * E * 6, 256);
+            OP(VIT_OP_OUT_PROJ, (rc = vh_launch_gather_rows(s, ctx->attn, attn_cls, 3 * (E / 32), rows, n, 64, T)) != 0 ? rc :
+                                (rc = vh_launch_gather_rows(s, ctx->x, x_cls, 1, rows, n, 4 * E, T)) != 0 ? rc :
+                                vh_launch_linear_p3(s, x_cls, 0, l3[4], attn_cls, lw[5], n, E, E, 0, x_cls));
+            OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, x_cls, lw[6], lw[7], y_cls, n, E, E, c->eps));
+            OP(VIT_OP_FC1, vh_launch_linear_p3(s, hid_cls, 1, l3[8], y_cls, lw[9], n, E, F, 1, NULL));
+            OP(VIT_OP_FC2, vh_launch_linear_p3(s, x_cls, 0, l3[10], hid_cls, lw[11], n, F, E, 0, x_cls));
+            final_x = x_cls;
+            final_stride = E;
+            break;
+        }
         OP(VIT_OP_OUT_PROJ, vh_launch_linear_p3(s, ctx->x, 0, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, c->eps));
         OP(VIT_OP_FC1, vh_launch_linear_p3(s, ctx->hid, 1, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL));
@@ -529,13 +557,22 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     /* final LayerNorm on the class-token rows, classifier, softmax (ViT_seq.c:506-515) */
     float **tw = w + 4 + 12 * c->depth;
     float *logits = d_logits ? d_logits : ctx->d_logits;
-    OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, tw[0], tw[1], ctx->cls, n, E, (long)T * E, E, c->eps));
+    OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, final_x, tw[0], tw[1], ctx->cls, n, E, final_stride, E, c->eps));
     OP(VIT_OP_HEAD, vh_launch_linear(s, logits, tw[2], ctx->cls, tw[3], n, E, NC, 0, NULL));
     if (d_probs)
         OP(VIT_OP_SOFTMAX, vh_launch_softmax(s, logits, d_probs, n, NC));
     return 0;
 fail:
     return rc;
+}
+
+int vit_hip_set_last_layer_cls_only(vit_hip_ctx *ctx, int on)
+{
+    if (!ctx)
+        return -1;
+    const int before = ctx->cls_only_last;
+    ctx->cls_only_last = on && ctx->use_p3;
+    return before;
 }
 
 /* Debug/test hook: copy the residual stream ([n*tokens][E]) to the host. */

@@ -241,6 +241,23 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float
     }
 }
 
+/* Every `stride`-th row of a row-major fp32 matrix / of each plane of a planes tensor, compacted: the class-token
+ * rows (row b * tokens of image b) that the classifier reads.  16 bytes per thread. */
+__global__ void gather_rows_kernel(const char *__restrict__ src, char *__restrict__ dst, int n_planes, int dst_rows,
+                                   size_t src_plane_bytes, int row_bytes, size_t src_row_stride_bytes)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = row_bytes >> 4;
+    const size_t total = (size_t)n_planes * dst_rows * per_row;
+    if (idx >= total)
+        return;
+    const int c = (int)(idx % per_row);
+    const size_t r = idx / per_row;
+    const int plane = (int)(r / dst_rows), row = (int)(r % dst_rows);
+    *reinterpret_cast<f32x4 *>(dst + ((size_t)plane * dst_rows + row) * row_bytes + 16 * c) =
+        *reinterpret_cast<const f32x4 *>(src + plane * src_plane_bytes + row * src_row_stride_bytes + 16 * c);
+}
+
 constexpr int SM_THREADS = 256;
 constexpr int SM_MAX_PER_THREAD = 8; /* rows up to 2048 entries stay in registers */
 
@@ -396,6 +413,22 @@ extern "C" int vh_launch_layer_norm_mx(vh_stream_t s, const float *input, const 
     else VH_LNMX(8);
 #undef VH_LNMX
     VH_LAUNCH_CHECK("layernorm_mx_kernel");
+    return 0;
+}
+
+/* dst[p][i][:] = src[p][i * row_stride][:] for n_planes planes of src_rows rows of row_bytes bytes each
+ * (n_planes = 1, row_bytes = 4 * cols: a row-major fp32 matrix; planes tensors: row_bytes = 64) */
+extern "C" int vh_launch_gather_rows(vh_stream_t s, const void *src, void *dst, int n_planes, int src_rows, int dst_rows,
+                                     int row_bytes, int row_stride)
+{
+    if (!src || !dst || n_planes <= 0 || src_rows <= 0 || dst_rows <= 0 || row_bytes <= 0 || row_bytes % 16 != 0 || row_stride <= 0 ||
+        (size_t)(dst_rows - 1) * row_stride >= (size_t)src_rows || (((uintptr_t)src | (uintptr_t)dst) & 15))
+        return vh_fail(1, "vh_launch_gather_rows: bad argument (row_bytes %% 16 == 0, (dst_rows-1)*row_stride < src_rows, 16-byte aligned)");
+    const size_t threads = (size_t)n_planes * dst_rows * (row_bytes / 16);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       static_cast<const char *>(src), static_cast<char *>(dst), n_planes, dst_rows, (size_t)src_rows * row_bytes,
+                       row_bytes, (size_t)row_stride * row_bytes);
+    VH_LAUNCH_CHECK("gather_rows_kernel");
     return 0;
 }
 

@@ -42,6 +42,7 @@ EXPORTS = [
     "vh_launch_attention_planes_bf16", "vh_launch_linear_planes", "vh_launch_attention_planes",
     "vh_launch_quantize_mx_rows", "vh_launch_linear_mx", "vh_launch_layer_norm_mx",
     "vh_launch_attention_planes_f16", "vh_launch_linear_mx_planes_f16", "vh_launch_attention_planes_f16_mx",
+    "vh_launch_gather_rows", "vit_hip_set_last_layer_cls_only",
     "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
     "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
@@ -165,6 +166,8 @@ def lib() -> C.CDLL:
     L.vh_launch_layer_norm_planes.argtypes = [voidp] + [voidp] * 4 + [i, i, i, C.c_long, C.c_double]
     L.vh_launch_attention_planes_bf16.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_attention_planes.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_gather_rows.argtypes = [voidp, voidp, voidp, i, i, i, i, i]
+    L.vit_hip_set_last_layer_cls_only.argtypes = [voidp, i]
     L.vh_launch_attention_planes_f16.argtypes = [voidp, voidp, voidp, i, i, i, i, i]
     L.vh_launch_attention_planes_f16_mx.argtypes = [voidp, voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_linear_mx_planes_f16.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, voidp, i, i, i]
@@ -362,6 +365,11 @@ class ViTHip:
 
     OP_NAMES = ["patch_embed", "layer_norm", "qkv_gemm", "attention", "out_proj_gemm", "fc1_gemm",
                 "fc2_gemm", "head_gemm", "softmax"]
+
+    def set_last_layer_cls_only(self, on: bool) -> bool:
+        """Opt-in: the last layer's output projection and MLP on the class-token rows only (identical logits).
+        Returns the previous setting."""
+        return bool(self.L.vit_hip_set_last_layer_cls_only(self.ctx, 1 if on else 0))
 
     def profile_enable(self, max_forwards: int):
         check(self.L.vit_hip_profile_enable(self.ctx, max_forwards), "vit_hip_profile_enable")
