@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
          * is fetched under the six MFMAs of step f (left alone, the compiler issues every read right before its
          * use and the matrix pipe waits out the LDS latency 28 times per item). */
         f32x16 s[NKT];
-        part_t kp[2][NPL];
+        part_t kp[3][NPL];
         auto read_k = [&](part_t (&k3)[NPL], int f) {
             const int j = f / (HD / 16), g = f % (HD / 16);
 #pragma unroll
@@ -144,6 +144,8 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
             }
         };
         read_k(kp[0], 0);
+        if (NKT * (HD / 16) > 1)
+            read_k(kp[1], 1);
 #pragma unroll
         for (int f = 0; f < NKT * (HD / 16); ++f) {
             const int j = f / (HD / 16), g = f % (HD / 16);
@@ -152,11 +154,11 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
                 for (int r = 0; r < 16; ++r)
                     s[j][r] = 0.0f;
             }
-            if (f + 1 < NKT * (HD / 16))
-                read_k(kp[(f + 1) & 1], f + 1);
+            if (f + 2 < NKT * (HD / 16))
+                read_k(kp[(f + 2) % 3], f + 2);          /* two steps (12 MFMAs) ahead: one step does not cover the LDS latency */
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                s[j] = mfma_part(kp[f & 1][term_w<NPL>(t)], qp[g][term_a<NPL>(t)], s[j]);
+                s[j] = mfma_part(kp[f % 3][term_w<NPL>(t)], qp[g][term_a<NPL>(t)], s[j]);
             if (NPL == 3) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
