@@ -749,3 +749,21 @@ def test_switchable_paths_meet_the_fp32_parity(env, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, f"{env}: {r.stdout[-300:]} {r.stderr[-800:]}"
+
+
+@pytest.mark.parametrize("n_images,tokens,E,H", [(2, 257, 1280, 16), (1, 50, 1280, 16), (3, 300, 256, 2)])
+def test_streaming_attention_with_fp16_operands_stays_within_the_reduced_modes_tolerance(pkg, device, oracle, n_images, tokens, E, H):
+    """vh_launch_attention_f16 on shapes of the streaming kernel (head_dim 80 / 128, T > 208: ViT-H/14): Q, K, V and
+    the probabilities rounded to fp16, one v_mfma_f32_16x16x16_f16 per four fp32 steps.  Against the fp32 streaming
+    kernel (itself checked against the oracle above) the result differs by the operands' rounding only:
+    |d| <= 2^-9 of the largest output magnitude (11-bit operands, sums of positive weights <= 1)."""
+    rows = n_images * tokens
+    qkv = oracle.synth_fill(rows * 3 * E, 911 + tokens, 1.0, 0.0)
+    d_q, d_a, d_b = _dev(pkg, qkv), pkg.DeviceBuffer(rows * E), pkg.DeviceBuffer(rows * E)
+    _launch(pkg, "vh_launch_attention", None, d_q.ptr, d_a.ptr, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_attention_f16", None, d_q.ptr, d_b.ptr, n_images, tokens, E, H)
+    a, b = d_a.to_numpy((rows, E)), d_b.to_numpy((rows, E))
+    assert np.isfinite(b).all()
+    err = np.abs(a - b).max()
+    print("fp16-operand streaming attention: max |d| =", err, "of", np.abs(a).max())
+    assert 0 < err <= 2.0 ** -9 * np.abs(a).max()

@@ -490,7 +490,7 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
             OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16(s, ctx->qkv, ctx->attn, 1, n, T, E, c->num_heads));
         } else {   /* shapes of the streaming attention kernel: fp32 output (into the idle MLP buffer), then rounded into planes */
             OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 0, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
-            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
                                  vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
         }
         OP(VIT_OP_OUT_PROJ, vh_launch_linear_planes(s, ctx->x, 0, lw16[4], ctx->attn, 1, lw[5], rows, E, E, 0, ctx->x));

@@ -456,8 +456,8 @@ static int launch_attention(vh_stream_t s, const float *qkv, void *output, int o
         const char *env = getenv("VIT_HIP_ATTN");
         force_tiled = (env && env[0] == 't') ? 1 : 0;
     }
-    if (embed_dim != num_heads * HD || tokens > MAX_ROWS || (force_tiled && out_bf16 < 3))
-        return vh_attention_tiled(s, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    if (embed_dim != num_heads * HD || tokens > MAX_ROWS || (force_tiled && out_bf16 < 3))   /* arith 1: fp16 operands there too */
+        return vh_attention_tiled(s, qkv, output, out_bf16, arith == 1 && out_bf16 == 0, n_images, tokens, embed_dim, num_heads);
     static int native = -1;
     if (native < 0) {
         const char *env = getenv("VIT_HIP_GEMM_FP32");   /* "native": the fp32 matrix instruction here too */

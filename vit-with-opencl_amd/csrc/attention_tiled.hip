@@ -31,10 +31,37 @@
 namespace {
 
 constexpr int KC = 32;   /* keys per LDS chunk (two 16-key MFMA tiles) */
-constexpr int QB = 64;   /* queries per workgroup (4 waves x 16) */
+constexpr int QB_MIN = 64;   /* queries per workgroup = 16 x NW waves, NW = 4 or 6 (whichever leaves fewer idle waves in the last block) */
 
-template <int D, int NJ, bool OUTBF16> /* NJ 16-key tiles: T <= 16*NJ */
-__global__ __launch_bounds__(256, 2) void attention_tiled_kernel(const float *__restrict__ qkv,
+/* Workgroup barrier for LDS hand-overs only: this wave's LDS operations have completed (lgkmcnt), global loads stay
+ * in flight.  __syncthreads() is a full workgroup fence -- it also drains vmcnt, i.e. it waits at every chunk step
+ * for the prefetch issued a few hundred cycles earlier, which put the whole load latency into each of the 18 steps. */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4 to_half4(const f32x4 &v)
+{
+    half4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        asm("" : "+v"(x));   /* no multiply + convert fusion (fp32_split.h, split_parts): rounded twice everywhere */
+        h[e] = (_Float16)x;
+    }
+    return h;
+}
+
+/* LOWP (the reduced-precision GEMM modes only): Q, K, V and the probabilities are rounded to fp16 in registers and
+ * the four contraction steps of a lane group become ONE v_mfma_f32_16x16x16_f16 -- its lane layout (row l & 15,
+ * k = 4 (l >> 4) + i) is exactly the permuted contraction described above.  fp32 accumulation and softmax; the
+ * arithmetic of vh_launch_attention_f16 for head dimensions and token counts the resident kernels do not take. */
+template <int D, int NJ, bool OUTBF16, bool LOWP, int NW> /* NJ 16-key tiles: T <= 16*NJ; NW waves of 16 queries */
+__global__ __launch_bounds__(64 * NW, 2) void attention_tiled_kernel(const float *__restrict__ qkv,
                                                                  void *__restrict__ out, int T, int E, int H,
                                                                  int n_qblocks, float scale_log2e)
 {
@@ -42,7 +69,8 @@ __global__ __launch_bounds__(256, 2) void attention_tiled_kernel(const float *__
     constexpr int NC = (NJ + 1) / 2;             /* chunks */
     constexpr int DT = D / 16;                   /* 16-wide d tiles */
     constexpr int PIECES = KC * D / 4;           /* 16-byte pieces per chunk */
-    constexpr int PPT = (PIECES + 255) / 256;    /* per thread */
+    constexpr int NTH = 64 * NW, QB = 16 * NW;
+    constexpr int PPT = (PIECES + NTH - 1) / NTH;    /* per thread */
     static_assert(D % 16 == 0 && D <= 128, "head_dim");
 
     __shared__ __attribute__((aligned(16))) float lds[2][KC * DS];
@@ -58,47 +86,55 @@ __global__ __launch_bounds__(256, 2) void attention_tiled_kernel(const float *__
 
     /* this lane's query (MFMA column), the d values its lane group contracts */
     f32x4 qreg[DT];
+    half4 qh[DT];
     {
         const float *qp = base + (size_t)min(q_row, T - 1) * ld + 4 * g;
 #pragma unroll
-        for (int s = 0; s < DT; ++s)
+        for (int s = 0; s < DT; ++s) {
             qreg[s] = *reinterpret_cast<const f32x4 *>(qp + 16 * s);
+            if (LOWP)
+                qh[s] = to_half4(qreg[s]);
+        }
     }
 
-    f32x4 stage[PPT];
+    /* Two chunks are in flight in registers: a chunk's MFMAs take a few hundred cycles, its global loads one to two
+     * microseconds -- with one chunk ahead the loop ran at the load latency (18 chunk steps of ~2 us per workgroup). */
+    f32x4 stage[2][PPT];
+    /* piece p of a chunk = 16 bytes; threads past the last piece repeat it (same bytes to the same LDS address): a
+     * per-thread condition here becomes a branch on EXEC, and at its join the compiler drains every load in flight */
+    int prow[PPT], pch[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = min(tid + NTH * i, PIECES - 1);
+        prow[i] = p / (D / 4);
+        pch[i] = p - prow[i] * (D / 4);
+    }
     auto load_chunk = [&](int c, const float *src) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const int p = tid + 256 * i;
-            if (PIECES % 256 == 0 || p < PIECES) {
-                const int row = p / (D / 4), ch = p - row * (D / 4);
-                const int r = min(KC * c + row, T - 1);   /* rows past T: a finite copy, masked below */
-                stage[i] = *reinterpret_cast<const f32x4 *>(src + (size_t)r * ld + 4 * ch);
-            }
+            const int r = min(KC * c + prow[i], T - 1);   /* rows past T: a finite copy, masked below */
+            stage[c & 1][i] = *reinterpret_cast<const f32x4 *>(src + (size_t)r * ld + 4 * pch[i]);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int c) {   /* chunk c: registers stage[c & 1] -> LDS buffer c & 1 */
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int p = tid + 256 * i;
-            if (PIECES % 256 == 0 || p < PIECES) {
-                const int row = p / (D / 4), ch = p - row * (D / 4);
-                *reinterpret_cast<f32x4 *>(&lds[buf][row * DS + 4 * ch]) = stage[i];
-            }
-        }
+        for (int i = 0; i < PPT; ++i)
+            *reinterpret_cast<f32x4 *>(&lds[c & 1][prow[i] * DS + 4 * pch[i]]) = stage[c & 1][i];
     };
 
     /* ---- pass 1: S^T = K Q^T, all key tiles of this wave's 16 queries into registers ---- */
     f32x4 S[NJ];
     load_chunk(0, base + E);
+    if (NC > 1 && KC < T)
+        load_chunk(1, base + E);
     store_chunk(0);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (KC * c < T) { /* uniform */
             const bool more = c + 1 < NC && KC * (c + 1) < T;
-            if (more)
-                load_chunk(c + 1, base + E);
+            if (c + 2 < NC && KC * (c + 2) < T)
+                load_chunk(c + 2, base + E);             /* into the registers chunk c was stored from */
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * c + jj;
@@ -109,17 +145,21 @@ __global__ __launch_bounds__(256, 2) void attention_tiled_kernel(const float *__
 #pragma unroll
                         for (int s = 0; s < DT; ++s) {
                             const f32x4 kf = *reinterpret_cast<const f32x4 *>(kp + 16 * s);
+                            if (LOWP) {
+                                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(to_half4(kf), qh[s], acc, 0, 0, 0);
+                            } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qreg[s][e], acc, 0, 0, 0);
+                                for (int e = 0; e < 4; ++e)
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qreg[s][e], acc, 0, 0, 0);
+                            }
                         }
                     }
                     S[j] = acc;
                 }
             }
             if (more)
-                store_chunk((c + 1) & 1);
-            __syncthreads();
+                store_chunk(c + 1);
+            lds_barrier();
         } else {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
@@ -128,8 +168,10 @@ __global__ __launch_bounds__(256, 2) void attention_tiled_kernel(const float *__
         }
     }
 
-    /* first V chunk on its way while the softmax runs */
+    /* the first two V chunks on their way while the softmax runs */
     load_chunk(0, base + 2 * E);
+    if (NC > 1 && KC < T)
+        load_chunk(1, base + 2 * E);
 
     /* ---- row softmax per query: register r of tile j is key 16j + 4g + r ---- */
     float mx = -INFINITY;
@@ -167,28 +209,36 @@ __global__ __launch_bounds__(256, 2) void attention_tiled_kernel(const float *__
     for (int dt = 0; dt < DT; ++dt)
         O[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     store_chunk(0);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (KC * c < T) {
             const bool more = c + 1 < NC && KC * (c + 1) < T;
-            if (more)
-                load_chunk(c + 1, base + 2 * E);
+            if (c + 2 < NC && KC * (c + 2) < T)
+                load_chunk(c + 2, base + 2 * E);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * c + jj;
                 if (j < NJ && active && 16 * j < T) {
                     const float *vp = &lds[c & 1][(jj * 16 + 4 * g) * DS + l15];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    if (LOWP) {
+                        const half4 ph = to_half4(S[j]);
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt)
-                            O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[r * DS + 16 * dt], S[j][r], O[dt], 0, 0, 0);
+                            O[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(
+                                to_half4(f32x4{vp[16 * dt], vp[DS + 16 * dt], vp[2 * DS + 16 * dt], vp[3 * DS + 16 * dt]}), ph, O[dt], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int dt = 0; dt < DT; ++dt)
+                                O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[r * DS + 16 * dt], S[j][r], O[dt], 0, 0, 0);
+                    }
                 }
             }
             if (more)
-                store_chunk((c + 1) & 1);
-            __syncthreads();
+                store_chunk(c + 1);
+            lds_barrier();
         }
     }
 
@@ -208,48 +258,61 @@ __global__ __launch_bounds__(256, 2) void attention_tiled_kernel(const float *__
     }
 }
 
-template <int D, int NJ>
-int launch_nj(hipStream_t st, const float *qkv, void *out, int out_bf16, int n_images, int T, int E, int H)
+template <int D, int NJ, int NW>
+int launch_nw(hipStream_t st, const float *qkv, void *out, int out_bf16, int lowp, int n_images, int T, int E, int H)
 {
-    const int n_qblocks = (T + QB - 1) / QB;
-    const dim3 grid((unsigned)(n_images * H * n_qblocks)), block(256);
+    const int n_qblocks = (T + 16 * NW - 1) / (16 * NW);
+    const dim3 grid((unsigned)(n_images * H * n_qblocks)), block(64 * NW);
     const float c = 1.4426950408889634f / sqrtf((float)D);
-    if (out_bf16)
-        hipLaunchKernelGGL((attention_tiled_kernel<D, NJ, true>), grid, block, 0, st, qkv, out, T, E, H, n_qblocks, c);
+    if (lowp)
+        hipLaunchKernelGGL((attention_tiled_kernel<D, NJ, false, true, NW>), grid, block, 0, st, qkv, out, T, E, H, n_qblocks, c);
+    else if (out_bf16)
+        hipLaunchKernelGGL((attention_tiled_kernel<D, NJ, true, false, NW>), grid, block, 0, st, qkv, out, T, E, H, n_qblocks, c);
     else
-        hipLaunchKernelGGL((attention_tiled_kernel<D, NJ, false>), grid, block, 0, st, qkv, out, T, E, H, n_qblocks, c);
+        hipLaunchKernelGGL((attention_tiled_kernel<D, NJ, false, false, NW>), grid, block, 0, st, qkv, out, T, E, H, n_qblocks, c);
     VH_LAUNCH_CHECK("attention_tiled_kernel");
     return 0;
 }
 
+/* Four waves (64 queries) per workgroup: measured on ViT-H/14 (T = 257: 5 query blocks, the last with one busy
+ * wave) against 2, 3 and 6 waves -- 0.71 ms against 0.90, 0.92 and 0.95: fewer passes over K and V do not pay for
+ * fewer workgroups in flight. */
+template <int D, int NJ>
+int launch_nj(hipStream_t st, const float *qkv, void *out, int out_bf16, int lowp, int n_images, int T, int E, int H)
+{
+    return launch_nw<D, NJ, 4>(st, qkv, out, out_bf16, lowp, n_images, T, E, H);
+}
+
 template <int D>
-int launch_d(hipStream_t st, const float *qkv, void *out, int out_bf16, int n_images, int T, int E, int H)
+int launch_d(hipStream_t st, const float *qkv, void *out, int out_bf16, int lowp, int n_images, int T, int E, int H)
 {
     if (T <= 128)
-        return launch_nj<D, 8>(st, qkv, out, out_bf16, n_images, T, E, H);
+        return launch_nj<D, 8>(st, qkv, out, out_bf16, lowp, n_images, T, E, H);
     if (T <= 272)
-        return launch_nj<D, 17>(st, qkv, out, out_bf16, n_images, T, E, H);
-    return launch_nj<D, 32>(st, qkv, out, out_bf16, n_images, T, E, H);
+        return launch_nj<D, 17>(st, qkv, out, out_bf16, lowp, n_images, T, E, H);
+    return launch_nj<D, 32>(st, qkv, out, out_bf16, lowp, n_images, T, E, H);
 }
 
 } // namespace
 
 /* Called by vh_launch_attention / vh_launch_attention_bf16 (attention_f32.hip) for the shapes
  * outside the resident-K/V kernel; arguments are already checked for null / positivity. */
-int vh_attention_tiled(vh_stream_t s, const float *qkv, void *output, int out_bf16, int n_images, int tokens,
+int vh_attention_tiled(vh_stream_t s, const float *qkv, void *output, int out_bf16, int lowp, int n_images, int tokens,
                        int embed_dim, int num_heads)
 {
+    if (lowp && out_bf16)
+        return vh_fail(1, "vh_launch_attention: the fp16-operand streaming kernel writes fp32 rows only");
     const int D = embed_dim / num_heads;
-    if (D * num_heads != embed_dim || tokens > 512 || ((size_t)n_images * num_heads * ((tokens + QB - 1) / QB)) >> 31)
+    if (D * num_heads != embed_dim || tokens > 512 || ((size_t)n_images * num_heads * ((tokens + QB_MIN - 1) / QB_MIN)) >> 31)
         return vh_fail(1, "vh_launch_attention: embed=%d heads=%d tokens=%d outside the supported range "
                           "(head_dim 64 | 80 | 128, tokens <= 512)", embed_dim, num_heads, tokens);
     if ((((uintptr_t)qkv | (uintptr_t)output) & 15) != 0 || embed_dim % 4 != 0)
         return vh_fail(1, "vh_launch_attention: qkv / output must be 16-byte aligned");
     hipStream_t st = (hipStream_t)s;
     switch (D) {
-    case 64: return launch_d<64>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
-    case 80: return launch_d<80>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
-    case 128: return launch_d<128>(st, qkv, output, out_bf16, n_images, tokens, embed_dim, num_heads);
+    case 64: return launch_d<64>(st, qkv, output, out_bf16, lowp, n_images, tokens, embed_dim, num_heads);
+    case 80: return launch_d<80>(st, qkv, output, out_bf16, lowp, n_images, tokens, embed_dim, num_heads);
+    case 128: return launch_d<128>(st, qkv, output, out_bf16, lowp, n_images, tokens, embed_dim, num_heads);
     default:
         return vh_fail(1, "vh_launch_attention: head_dim %d is not built (64, 80, 128)", D);
     }

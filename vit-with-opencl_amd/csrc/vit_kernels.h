@@ -43,7 +43,7 @@ int vh_fail(int code, const char *fmt, ...);
 int vh_hip_status(hipError_t e, const char *what);
 
 /* attention_tiled.hip: the shapes the resident-K/V attention kernel does not take. */
-int vh_attention_tiled(void *stream, const float *qkv, void *output, int out_bf16, int n_images, int tokens,
+int vh_attention_tiled(void *stream, const float *qkv, void *output, int out_bf16, int lowp, int n_images, int tokens,
                        int embed_dim, int num_heads);
 
 /* Launch state that is per DEVICE (a process may hold contexts on several GPUs, one host thread each):
