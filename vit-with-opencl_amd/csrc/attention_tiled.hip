@@ -30,7 +30,8 @@
 
 namespace {
 
-constexpr int KC = 32;   /* keys per LDS chunk (two 16-key MFMA tiles) */
+constexpr int KC = 64;   /* keys per LDS chunk (four 16-key MFMA tiles) */
+constexpr int TPC = KC / 16;
 constexpr int QB_MIN = 64;   /* queries per workgroup = 16 x NW waves, NW = 4 or 6 (whichever leaves fewer idle waves in the last block) */
 
 /* Workgroup barrier for LDS hand-overs only: this wave's LDS operations have completed (lgkmcnt), global loads stay
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_tiled_kernel(const float
                                                                  int n_qblocks, float scale_log2e)
 {
     constexpr int DS = D + 4;                    /* LDS row stride in words */
-    constexpr int NC = (NJ + 1) / 2;             /* chunks */
+    constexpr int NC = (NJ + TPC - 1) / TPC;     /* chunks */
     constexpr int DT = D / 16;                   /* 16-wide d tiles */
     constexpr int PIECES = KC * D / 4;           /* 16-byte pieces per chunk */
     constexpr int NTH = 64 * NW, QB = 16 * NW;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_tiled_kernel(const float
 
     /* Two chunks are in flight in registers: a chunk's MFMAs take a few hundred cycles, its global loads one to two
      * microseconds -- with one chunk ahead the loop ran at the load latency (18 chunk steps of ~2 us per workgroup). */
-    f32x4 stage[2][PPT];
+    f32x4 stage[1][PPT];
     /* piece p of a chunk = 16 bytes; threads past the last piece repeat it (same bytes to the same LDS address): a
      * per-thread condition here becomes a branch on EXEC, and at its join the compiler drains every load in flight */
     int prow[PPT], pch[PPT];
@@ -113,31 +114,29 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_tiled_kernel(const float
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int r = min(KC * c + prow[i], T - 1);   /* rows past T: a finite copy, masked below */
-            stage[c & 1][i] = *reinterpret_cast<const f32x4 *>(src + (size_t)r * ld + 4 * pch[i]);
+            stage[0][i] = *reinterpret_cast<const f32x4 *>(src + (size_t)r * ld + 4 * pch[i]);
         }
     };
     auto store_chunk = [&](int c) {   /* chunk c: registers stage[c & 1] -> LDS buffer c & 1 */
 #pragma unroll
         for (int i = 0; i < PPT; ++i)
-            *reinterpret_cast<f32x4 *>(&lds[c & 1][prow[i] * DS + 4 * pch[i]]) = stage[c & 1][i];
+            *reinterpret_cast<f32x4 *>(&lds[c & 1][prow[i] * DS + 4 * pch[i]]) = stage[0][i];
     };
 
     /* ---- pass 1: S^T = K Q^T, all key tiles of this wave's 16 queries into registers ---- */
     f32x4 S[NJ];
     load_chunk(0, base + E);
-    if (NC > 1 && KC < T)
-        load_chunk(1, base + E);
     store_chunk(0);
     lds_barrier();
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (KC * c < T) { /* uniform */
             const bool more = c + 1 < NC && KC * (c + 1) < T;
-            if (c + 2 < NC && KC * (c + 2) < T)
-                load_chunk(c + 2, base + E);             /* into the registers chunk c was stored from */
+            if (more)
+                load_chunk(c + 1, base + E);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = 2 * c + jj;
+            for (int jj = 0; jj < TPC; ++jj) {
+                const int j = TPC * c + jj;
                 if (j < NJ) {
                     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (active && 16 * j < T) {
@@ -162,16 +161,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_tiled_kernel(const float
             lds_barrier();
         } else {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-                if (2 * c + jj < NJ)
-                    S[2 * c + jj] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int jj = 0; jj < TPC; ++jj)
+                if (TPC * c + jj < NJ)
+                    S[TPC * c + jj] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
 
     /* the first two V chunks on their way while the softmax runs */
     load_chunk(0, base + 2 * E);
-    if (NC > 1 && KC < T)
-        load_chunk(1, base + 2 * E);
 
     /* ---- row softmax per query: register r of tile j is key 16j + 4g + r ---- */
     float mx = -INFINITY;
@@ -214,11 +211,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_tiled_kernel(const float
     for (int c = 0; c < NC; ++c) {
         if (KC * c < T) {
             const bool more = c + 1 < NC && KC * (c + 1) < T;
-            if (c + 2 < NC && KC * (c + 2) < T)
-                load_chunk(c + 2, base + 2 * E);
+            if (more)
+                load_chunk(c + 1, base + 2 * E);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = 2 * c + jj;
+            for (int jj = 0; jj < TPC; ++jj) {
+                const int j = TPC * c + jj;
                 if (j < NJ && active && 16 * j < T) {
                     const float *vp = &lds[c & 1][(jj * 16 + 4 * g) * DS + l15];
                     if (LOWP) {
