@@ -306,3 +306,38 @@ def test_public_headers_are_plain_c_and_cxx(tmp_path):
             r = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", f"-I{root / 'include'}", str(src)],
                                capture_output=True, text=True)
             assert r.returncode == 0, f"{hdr} as {lang}: {r.stderr[-800:]}"
+
+
+def test_mx_reference_scale_rule_layout_and_torch_cross_check():
+    """tests/mx_ref.py, the numpy statement the GPU's block-scaled fp8 producers are compared with byte for byte:
+    (i) the scale of a block is the SMALLEST power of two that brings its maximum inside e4m3's range (<= 448), so
+    nothing saturates and no smaller scale would do; (ii) the elements are torch's float8_e4m3fn cast of x / scale;
+    (iii) dequantise(quantise(x)) is within half an e4m3 step of the block maximum's binade; (iv) the storage order
+    values[K/128][rows][128], scales[K/128][4][rows] with block b in lane-group slot 2 (b & 1) + (b >> 1)."""
+    torch = pytest.importorskip("torch")
+    import mx_ref
+    rng = np.random.default_rng(11)
+    rows, cols = 64, 512
+    x = (rng.standard_normal((rows, cols)) * np.exp(rng.uniform(-12, 12, (rows, cols // 32)).repeat(32, axis=1))).astype(np.float32)
+    x[3, 64:96] = 0.0                                              # an all-zero block
+    x[5, 0] = np.float32(1.8 * 2.0 ** 9)                           # maximum with a significand above 1.75: exponent one up
+    values, scales = mx_ref.quantize(x)
+    assert values.shape == (cols // 128, rows, 128) and scales.shape == (cols // 128, 4, rows)
+    blocks = x.reshape(rows, cols // 32, 32)
+    amax = np.abs(blocks).max(axis=2).astype(np.float64)
+    # undo the storage order
+    sb = np.empty((rows, cols // 128, 4), dtype=np.int32)
+    for b in range(4):
+        sb[:, :, b] = scales[:, 2 * (b & 1) + (b >> 1), :].T.astype(np.int32) - 127
+    e = sb.reshape(rows, cols // 32)
+    live = amax > 2.0 ** -118
+    assert (amax[live] / 2.0 ** e[live] <= 448.0).all()                       # nothing clips
+    assert (amax[live] / 2.0 ** (e[live] - 1) > 448.0).all()                  # and no smaller scale would do
+    assert (e[~live] == -126).all()
+    q = values.transpose(1, 0, 2).reshape(rows, cols // 32, 32)
+    scaled = (blocks * np.ldexp(np.float32(1.0), -e)[:, :, None].astype(np.float32)).astype(np.float32)
+    want = torch.from_numpy(scaled).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    zero = (want & 0x7f) == 0
+    assert np.array_equal(q[~zero], want[~zero]) and np.array_equal(q[zero] & 0x7f, want[zero] & 0x7f)
+    back = mx_ref.dequantize(values, scales).reshape(rows, cols // 32, 32)
+    assert (np.abs(back - blocks) <= 2.0 ** -4 * np.maximum(amax, 2.0 ** -126)[:, :, None] * 1.0000001).all()
