@@ -24,6 +24,12 @@ core; the images are chosen to straddle the GPU path's tile and launch boundarie
 and their logits give the parity of the GPU result in the same run.
 `end_to_end` is the host-pointer entry vit_hip_forward (separately allocated host
 images in, probabilities out, PCIe included) -- reported beside `value`, never as it.
+At N = 1 and the default dtype the line also carries secondary legs, each beside and
+never instead of `value`: the opt-in reduced-precision modes (`bf16_gemm_mode`,
+`fp8_block_scaled_gemm_mode`, `fp32_fp16x2_emulation_mode`, each with its own
+`roofline` block) and `class_token_rows_only_last_layer` (the opt-in that evaluates
+the last layer's projection and MLP on the rows the classifier reads; logits checked
+bit for bit against the full evaluation in the same run).
 """
 from __future__ import annotations
 
