@@ -93,7 +93,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
  * planes' own order, [K step][part][16 rows][64 B], so that every global store instruction writes one
  * contiguous, aligned KiB (16 rows x 64 B of one K step and part) instead of eight 64-byte pieces 19 MB apart. */
 constexpr int LN3_ROWS = 16;
-template <int NV, int NPL>   /* NPL parts per value: 3 = exact split, 1 = rounded to bf16 (the bf16-operand mode) */
+
+/* Workgroup barrier for LDS hand-overs only (lgkmcnt): global loads stay in flight across it.  __syncthreads() is a
+ * full fence and drains vmcnt, i.e. it would wait for the NEXT row group's loads issued a moment earlier. */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+/* Persistent: a workgroup walks row groups blockIdx.x, blockIdx.x + gridDim.x, ... and loads the rows of the next
+ * group before it normalises, stages and stores the current one -- with one group per workgroup the loads of a
+ * workgroup were in flight for less than half of its lifetime and the kernel ran at the load latency, not at the
+ * HBM rate.  FULL: every lane holds NV valid chunks (E = 256 NV: 768, 1024, 1280): no per-lane condition anywhere. */
+template <int NV, int NPL, bool FULL>   /* NPL parts per value: 3 = exact split, 1 = rounded to bf16 (the bf16-operand mode) */
 __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float *__restrict__ in,
                                                                     const float *__restrict__ gamma,
                                                                     const float *__restrict__ beta,
@@ -102,17 +116,24 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float
 {
     extern __shared__ __attribute__((aligned(16))) char ln_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * LN3_ROWS, row = row0 + wave;
     const int nvec = E >> 2;
-    if (row < rows) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)row * in_stride);
-        f32x4 x[NV];
+    const int ngroups = (rows + LN3_ROWS - 1) / LN3_ROWS, stride = gridDim.x;
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+
+    auto load_rows = [&](f32x4 (&x)[NV], int group) {   /* unconditional: rows / chunks past the end repeat the last one */
+        const int r = min(group * LN3_ROWS + wave, rows - 1);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)r * in_stride);
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+            x[c] = src[FULL ? c * 64 + lane : min(c * 64 + lane, nvec - 1)];
+    };
+    auto process = [&](const f32x4 (&x)[NV], int group) {
+        const int row0 = group * LN3_ROWS;
         float sum = 0.0f, sq = 0.0f;
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
-            const int idx = c * 64 + lane;
-            if (idx < nvec) {
-                x[c] = src[idx];
+            if (FULL || c * 64 + lane < nvec) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     sum += x[c][e];
@@ -125,12 +146,10 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float
         const float mean = sum / (float)E;
         const float var = sq / (float)E - mean * mean;
         const float inv_std = 1.0f / sqrtf((float)((double)var + eps));
-        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
-        const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
             const int idx = c * 64 + lane;
-            if (idx < nvec) {
+            if (FULL || idx < nvec) {
                 const f32x4 g = g4[idx], bb = b4[idx];
                 f32x4 y;
 #pragma unroll
@@ -147,21 +166,41 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float
                     *reinterpret_cast<bf16x4 *>(d + pl * LN3_ROWS * 64) = part[pl];
             }
         }
+        lds_barrier();
+        /* copy-out: piece = (K step, part) = 1 KiB = 16 rows x 64 B; lane l moves 16 bytes of row l / 4 */
+        const int pieces = (E >> 5) * NPL;
+        if (row0 + (lane >> 2) < rows)
+            for (int pc = wave; pc < pieces; pc += LN3_ROWS)
+                *reinterpret_cast<f32x4 *>(planes + ((size_t)pc * rows + row0) * 64 + 16 * lane) =
+                    *reinterpret_cast<const f32x4 *>(ln_lds + pc * 1024 + 16 * lane);
+        lds_barrier();                                   /* the image is free for the next group */
+    };
+
+    f32x4 xa[NV], xb[NV];
+    int g0 = blockIdx.x;
+    if (g0 >= ngroups)
+        return;
+    load_rows(xa, g0);
+    for (;;) {
+        const int g1 = g0 + stride;
+        load_rows(xb, min(g1, ngroups - 1));
+        process(xa, g0);
+        if (g1 >= ngroups)
+            break;
+        const int g2 = g1 + stride;
+        load_rows(xa, min(g2, ngroups - 1));
+        process(xb, g1);
+        if (g2 >= ngroups)
+            break;
+        g0 = g2;
     }
-    __syncthreads();
-    /* copy-out: piece = (K step, part) = 1 KiB = 16 rows x 64 B; lane l moves 16 bytes of row l / 4 */
-    const int pieces = (E >> 5) * NPL;
-    if (row0 + (lane >> 2) < rows)
-        for (int pc = wave; pc < pieces; pc += LN3_ROWS)
-            *reinterpret_cast<f32x4 *>(planes + ((size_t)pc * rows + row0) * 64 + 16 * lane) =
-                *reinterpret_cast<const f32x4 *>(ln_lds + pc * 1024 + 16 * lane);
 }
 
 /* LayerNorm whose only consumer is the block-scaled fp8 GEMM (gemm_mx.hip): one wave per row as above; a lane
  * holds 4 consecutive values, the 8 lanes 8m .. 8m+7 one 32-element scale block (three shuffles for its maximum);
  * values and scales go through an LDS image in the MX planes' own order ([K step][16 rows][128 B], then
  * [K step][4][16 rows] scale bytes) so that the global stores are contiguous 2 KiB / 16-byte runs. */
-template <int NV>
+template <int NV, bool FULL>   /* persistent and FULL as layernorm_p3_kernel */
 __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float *__restrict__ in, const float *__restrict__ gamma,
                                                                     const float *__restrict__ beta, char *__restrict__ values,
                                                                     unsigned char *__restrict__ scales, int rows, int E,
@@ -169,18 +208,25 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float
 {
     extern __shared__ __attribute__((aligned(16))) char ln_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * LN3_ROWS, row = row0 + wave;
     const int nvec = E >> 2, ksteps = E >> 7;
     char *lds_scales = ln_lds + ksteps * LN3_ROWS * 128;
-    if (row < rows) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)row * in_stride);
-        f32x4 x[NV];
+    const int ngroups = (rows + LN3_ROWS - 1) / LN3_ROWS, stride = gridDim.x;
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+
+    auto load_rows = [&](f32x4 (&x)[NV], int group) {
+        const int r = min(group * LN3_ROWS + wave, rows - 1);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)r * in_stride);
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+            x[c] = src[FULL ? c * 64 + lane : min(c * 64 + lane, nvec - 1)];
+    };
+    auto process = [&](const f32x4 (&x)[NV], int group) {
+        const int row0 = group * LN3_ROWS;
         float sum = 0.0f, sq = 0.0f;
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
-            const int idx = c * 64 + lane;
-            if (idx < nvec) {
-                x[c] = src[idx];
+            if (FULL || c * 64 + lane < nvec) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     sum += x[c][e];
@@ -193,12 +239,10 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float
         const float mean = sum / (float)E;
         const float var = sq / (float)E - mean * mean;
         const float inv_std = 1.0f / sqrtf((float)((double)var + eps));
-        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
-        const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
             const int idx = c * 64 + lane;
-            if (idx < nvec) {          /* E % 128 == 0: whole groups of 8 lanes are in or out together */
+            if (FULL || idx < nvec) {          /* E % 128 == 0: whole groups of 8 lanes are in or out together */
                 const f32x4 g = g4[idx], bb = b4[idx];
                 f32x4 y;
                 float amax = 0.0f;
@@ -219,25 +263,45 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float
                     lds_scales[(ks * 4 + 2 * (blk & 1) + (blk >> 1)) * LN3_ROWS + wave] = (char)sbyte;
             }
         }
-    }
-    __syncthreads();
-    /* copy-out: values piece = half a K step's image (8 rows x 128 B = 1 KiB, lane moves 16 B of row l / 8);
-     * scales: one 16-byte run (16 rows) per (K step, lane group) */
-    const int vpieces = ksteps * 2;
-    for (int pc = wave; pc < vpieces; pc += LN3_ROWS) {
-        const int ks = pc >> 1, r = 8 * (pc & 1) + (lane >> 3);
-        if (row0 + r < rows)
-            *reinterpret_cast<f32x4 *>(values + ((size_t)ks * rows + row0 + r) * 128 + 16 * (lane & 7)) =
-                *reinterpret_cast<const f32x4 *>(ln_lds + (ks * LN3_ROWS + r) * 128 + 16 * (lane & 7));
-    }
-    if (threadIdx.x < ksteps * 4) {
-        unsigned char *dst = scales + (size_t)threadIdx.x * rows + row0;
-        const char *srcs = lds_scales + threadIdx.x * LN3_ROWS;
-        if (row0 + LN3_ROWS <= rows && (((uintptr_t)dst) & 15) == 0)
-            *reinterpret_cast<f32x4 *>(dst) = *reinterpret_cast<const f32x4 *>(srcs);
-        else
-            for (int r = 0; r < LN3_ROWS && row0 + r < rows; ++r)
-                dst[r] = (unsigned char)srcs[r];
+        lds_barrier();
+        /* copy-out: values piece = half a K step's image (8 rows x 128 B = 1 KiB, lane moves 16 B of row l / 8);
+         * scales: one 16-byte run (16 rows) per (K step, lane group) */
+        const int vpieces = ksteps * 2;
+        for (int pc = wave; pc < vpieces; pc += LN3_ROWS) {
+            const int ks = pc >> 1, r = 8 * (pc & 1) + (lane >> 3);
+            if (row0 + r < rows)
+                *reinterpret_cast<f32x4 *>(values + ((size_t)ks * rows + row0 + r) * 128 + 16 * (lane & 7)) =
+                    *reinterpret_cast<const f32x4 *>(ln_lds + (ks * LN3_ROWS + r) * 128 + 16 * (lane & 7));
+        }
+        if (threadIdx.x < ksteps * 4) {
+            unsigned char *dst = scales + (size_t)threadIdx.x * rows + row0;
+            const char *srcs = lds_scales + threadIdx.x * LN3_ROWS;
+            if (row0 + LN3_ROWS <= rows && (((uintptr_t)dst) & 15) == 0)
+                *reinterpret_cast<f32x4 *>(dst) = *reinterpret_cast<const f32x4 *>(srcs);
+            else
+                for (int r = 0; r < LN3_ROWS && row0 + r < rows; ++r)
+                    dst[r] = (unsigned char)srcs[r];
+        }
+        lds_barrier();
+    };
+
+    f32x4 xa[NV], xb[NV];
+    int g0 = blockIdx.x;
+    if (g0 >= ngroups)
+        return;
+    load_rows(xa, g0);
+    for (;;) {
+        const int g1 = g0 + stride;
+        load_rows(xb, min(g1, ngroups - 1));
+        process(xa, g0);
+        if (g1 >= ngroups)
+            break;
+        const int g2 = g1 + stride;
+        load_rows(xa, min(g2, ngroups - 1));
+        process(xb, g1);
+        if (g2 >= ngroups)
+            break;
+        g0 = g2;
     }
 }
 
@@ -358,13 +422,23 @@ extern "C" int vh_launch_layer_norm_planes(vh_stream_t s, const float *input, co
         return vh_fail(1, "vh_launch_layer_norm_planes: row stride must be a multiple of 4 floats and >= embed_dim");
     const int nv = (embed_dim / 4 + 63) / 64;
     const size_t lds = (size_t)(embed_dim / 32) * parts * LN3_ROWS * 64;
-    const dim3 grid((rows + LN3_ROWS - 1) / LN3_ROWS), block(64 * LN3_ROWS);
+    const int ngroups = (rows + LN3_ROWS - 1) / LN3_ROWS;
+    const int resident = (160 * 1024) / (int)lds < 2 ? 1 : 2;            /* workgroups of 1024 threads per CU */
+    const int cap = resident * vh_device_cus(vh_current_device());
+    const dim3 grid(ngroups < cap ? ngroups : cap), block(64 * LN3_ROWS);
     hipStream_t st = (hipStream_t)s;
+#define VH_LN3_F(NV, NPL, FULL)                                                                           \
+    do {                                                                                                  \
+        VH_SET_LDS_ONCE((layernorm_p3_kernel<NV, NPL, FULL>), 160 * 1024);                                \
+        hipLaunchKernelGGL((layernorm_p3_kernel<NV, NPL, FULL>), grid, block, lds, st, input, weight, bias, \
+                           static_cast<char *>(out_planes), rows, embed_dim, in_row_stride, eps);         \
+    } while (0)
 #define VH_LN3_K(NV, NPL)                                                                                 \
     do {                                                                                                  \
-        VH_SET_LDS_ONCE((layernorm_p3_kernel<NV, NPL>), 160 * 1024);                                      \
-        hipLaunchKernelGGL((layernorm_p3_kernel<NV, NPL>), grid, block, lds, st, input, weight, bias,     \
-                           static_cast<char *>(out_planes), rows, embed_dim, in_row_stride, eps);         \
+        if (embed_dim == 256 * (NV))                                                                      \
+            VH_LN3_F(NV, NPL, true);                                                                      \
+        else                                                                                              \
+            VH_LN3_F(NV, NPL, false);                                                                     \
     } while (0)
 #define VH_LN3(NV)                                                                                        \
     do {                                                                                                  \
@@ -379,6 +453,7 @@ extern "C" int vh_launch_layer_norm_planes(vh_stream_t s, const float *input, co
     else VH_LN3(8);
 #undef VH_LN3
 #undef VH_LN3_K
+#undef VH_LN3_F
     VH_LAUNCH_CHECK("layernorm_p3_kernel");
     return 0;
 }
@@ -401,17 +476,27 @@ extern "C" int vh_launch_layer_norm_mx(vh_stream_t s, const float *input, const 
         return vh_fail(1, "vh_launch_layer_norm_mx: row stride must be a multiple of 4 floats and >= embed_dim");
     const int nv = (embed_dim / 4 + 63) / 64;
     const size_t lds = (size_t)(embed_dim / 128) * LN3_ROWS * (128 + 4);
-    const dim3 grid((rows + LN3_ROWS - 1) / LN3_ROWS), block(64 * LN3_ROWS);
+    const int ngroups = (rows + LN3_ROWS - 1) / LN3_ROWS;
+    const int cap = 2 * vh_device_cus(vh_current_device());               /* two workgroups of 1024 threads per CU */
+    const dim3 grid(ngroups < cap ? ngroups : cap), block(64 * LN3_ROWS);
     hipStream_t st = (hipStream_t)s;
-#define VH_LNMX(NV)                                                                                           \
-    hipLaunchKernelGGL((layernorm_mx_kernel<NV>), grid, block, lds, st, input, weight, bias,                   \
+#define VH_LNMX_F(NV, FULL)                                                                                    \
+    hipLaunchKernelGGL((layernorm_mx_kernel<NV, FULL>), grid, block, lds, st, input, weight, bias,             \
                        static_cast<char *>(out_values), static_cast<unsigned char *>(out_scales), rows,      \
                        embed_dim, in_row_stride, eps)
+#define VH_LNMX(NV)                                                                                            \
+    do {                                                                                                       \
+        if (embed_dim == 256 * (NV))                                                                           \
+            VH_LNMX_F(NV, true);                                                                               \
+        else                                                                                                   \
+            VH_LNMX_F(NV, false);                                                                              \
+    } while (0)
     if (nv <= 3) VH_LNMX(3);
     else if (nv <= 4) VH_LNMX(4);
     else if (nv <= 5) VH_LNMX(5);
     else VH_LNMX(8);
 #undef VH_LNMX
+#undef VH_LNMX_F
     VH_LAUNCH_CHECK("layernorm_mx_kernel");
     return 0;
 }
