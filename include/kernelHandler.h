@@ -173,6 +173,10 @@ int vh_launch_attention_planes(vh_stream_t s, const void *qkv_planes, void *out_
  * (same results bit for bit on the same fp16 values); head_dim 64, tokens <= 208. */
 int vh_launch_attention_planes_f16(vh_stream_t s, const void *qkv_planes_f16, void *output, int output_planes,
                                    int n_images, int tokens, int embed_dim, int num_heads);
+/* The same arithmetic for ViT-H/14's shape (head_dim 80, tokens <= 272) with one head's K and V resident in LDS
+ * (csrc/attention_h16.hip): qkv_planes_f16 as above -> fp32 rows [n_images*tokens][embed_dim]. */
+int vh_launch_attention_planes_f16_hd80(vh_stream_t s, const void *qkv_planes_f16, float *output, int n_images,
+                                        int tokens, int embed_dim, int num_heads);
 /* vh_launch_linear on planes: input_planes [colA/32][3][rowA][32], weight_planes [colA/32][3][colB][32];
  * output fp32 [rowA][colB], or (output_planes != 0, no residual) planes [colB/32][3][rowA][32].
  * colA % 64 == 0, colB % 128 == 0. */

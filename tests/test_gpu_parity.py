@@ -767,3 +767,31 @@ def test_streaming_attention_with_fp16_operands_stays_within_the_reduced_modes_t
     err = np.abs(a - b).max()
     print("fp16-operand streaming attention: max |d| =", err, "of", np.abs(a).max())
     assert 0 < err <= 2.0 ** -9 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("n_images,tokens", [(2, 257), (1, 50), (40, 257), (3, 272), (1, 1)])
+def test_resident_fp16_planes_attention_for_head_dim_80(pkg, device, oracle, n_images, tokens):
+    """vh_launch_attention_planes_f16_hd80 (ViT-H/14's shape, K and V resident in LDS as fp16 planes) against
+    vh_launch_attention_f16 on fp32 rows (the streaming kernel's fp16-operand form): the same operand rounding and
+    softmax, another summation order -- |d| <= 2^-12 of the largest output magnitude -- and against the fp32
+    streaming kernel within the operands' rounding (2^-9).  Several items per workgroup (40 x 16 on 256 workgroups),
+    both rounds of query tiles, an odd and an even head offset in every image."""
+    E, H = 1280, 16
+    rows = n_images * tokens
+    qkv = oracle.synth_fill(rows * 3 * E, 1011 + tokens, 1.0, 0.0).reshape(rows, 3 * E)
+    d_q = _dev(pkg, qkv)
+    planes = np.ascontiguousarray(qkv.astype(np.float16).reshape(rows, 3 * E // 32, 32).transpose(1, 0, 2))
+    d_qh = pkg.DeviceBuffer.from_numpy(planes.ravel().view(np.float32))
+    d_a, d_b, d_c = pkg.DeviceBuffer(rows * E), pkg.DeviceBuffer(rows * E), pkg.DeviceBuffer(rows * E)
+    _launch(pkg, "vh_launch_attention", None, d_q.ptr, d_a.ptr, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_attention_f16", None, d_q.ptr, d_b.ptr, n_images, tokens, E, H)
+    _launch(pkg, "vh_launch_attention_planes_f16_hd80", None, d_qh.ptr, d_c.ptr, n_images, tokens, E, H)
+    a, b, c = d_a.to_numpy((rows, E)), d_b.to_numpy((rows, E)), d_c.to_numpy((rows, E))
+    assert np.isfinite(c).all()
+    big = np.abs(a).max()
+    print("resident fp16 attention: max |d| vs streaming fp16 form", np.abs(c - b).max(), "vs fp32", np.abs(c - a).max(), "of", big)
+    assert np.abs(c - b).max() <= 2.0 ** -12 * big
+    assert np.abs(c - a).max() <= 2.0 ** -9 * big
+    L = pkg.lib()
+    assert L.vh_launch_attention_planes_f16_hd80(None, d_qh.ptr, d_c.ptr, n_images, 273, E, H) != 0
+    assert L.vh_launch_attention_planes_f16_hd80(None, d_qh.ptr, d_c.ptr, n_images, tokens, 1024, H) != 0
