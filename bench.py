@@ -393,6 +393,10 @@ def main() -> None:
         else:
             peak_tf, peak_note = 2500.0 / 6.0, ("dense bf16 MFMA peak / 6: six bf16 MFMAs per fp32-equivalent "
                                                 "product block; the native fp32 MFMA peak is 157.3")
+        # MFMA utilisation of every projection GEMM against the same peak (the north star asks for it on QKV / MLP)
+        for gname in ("qkv_gemm", "out_proj_gemm", "fc1_gemm", "fc2_gemm"):
+            if gname in kernels and "tflops" in kernels[gname]:
+                kernels[gname]["frac_mfma_peak"] = round(kernels[gname]["tflops"] / peak_tf, 4)
         # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes
         # (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); bench.py cannot collect PMCs itself.
         p3 = args.dtype == "f32" and not native and os.environ.get("VIT_HIP_P3", "1") != "0"
