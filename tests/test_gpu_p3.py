@@ -250,6 +250,26 @@ def test_model_p3_full_batch_tile_paths(pkg, device, weights):
     assert np.array_equal(lb[pick], ls)
 
 
+def test_benchmark_batch_of_512_gives_every_image_its_small_batch_logits(pkg, device, weights, golden_full):
+    """BASELINE's measured configuration itself (ViT-B/16, 512 images, M = 100 864 rows: every projection on its
+    big-tile launch plus tail launch, the persistent attention and LayerNorm grids several items deep): the logits of
+    images at the tile and launch boundaries (row 98 304, where fc1's and QKV's 256x256-tile launches hand over to
+    128x128 tiles, is in image 499; fc2's hand-over row 87 296 in image 443) equal, bit for bit, those of the same
+    images run eight at a time, and the first four are within 1e-4 of ViT_seq.c's."""
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 0, 512)
+    big = pkg.ViTHip(cfg, weights, device=0, max_batch=512)
+    lb, pb = big.forward(imgs)
+    big.close()
+    pick = [0, 1, 255, 442, 443, 498, 499, 511]
+    small = pkg.ViTHip(cfg, weights, device=0, max_batch=8)
+    ls, ps = small.forward(imgs[pick])
+    small.close()
+    assert np.array_equal(lb[pick], ls) and np.array_equal(pb[pick], ps)
+    assert np.abs(lb[:4] - golden_full["logits"][:4]).max() <= 1e-4
+    assert np.isfinite(lb).all() and np.abs(pb.sum(axis=1) - 1.0).max() < 1e-5
+
+
 # ---- the same kernel with ONE part per value: the bf16-operand mode (BASELINE config 3) -----------
 
 
