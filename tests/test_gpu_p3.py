@@ -270,6 +270,22 @@ def test_benchmark_batch_of_512_gives_every_image_its_small_batch_logits(pkg, de
     assert np.isfinite(lb).all() and np.abs(pb.sum(axis=1) - 1.0).max() < 1e-5
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_reduced_modes_at_batch_512_are_batch_position_independent(pkg, device, weights, precision):
+    """BASELINE config 3's size in its own precision (and the fp8 mode): big-tile launches, tail launches and the
+    persistent grids give an image the same logits, bit for bit, as a batch of four does."""
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 0, 512)
+    big = pkg.ViTHip(cfg, weights, device=0, max_batch=512, precision=precision)
+    lb, _ = big.forward(imgs)
+    big.close()
+    pick = [0, 255, 499, 511]
+    small = pkg.ViTHip(cfg, weights, device=0, max_batch=4, precision=precision)
+    ls, _ = small.forward(imgs[pick])
+    small.close()
+    assert np.isfinite(lb).all() and np.array_equal(lb[pick], ls)
+
+
 # ---- the same kernel with ONE part per value: the bf16-operand mode (BASELINE config 3) -----------
 
 
