@@ -270,6 +270,33 @@ def test_benchmark_batch_of_512_gives_every_image_its_small_batch_logits(pkg, de
     assert np.isfinite(lb).all() and np.abs(pb.sum(axis=1) - 1.0).max() < 1e-5
 
 
+def test_linear_p3_with_a_permutation_matrix_moves_columns_exactly_at_full_size(pkg, device, oracle):
+    """A size-independent property at the benchmark's M = 100 864: with W a (column-selecting) 0/1 matrix and zero bias
+    every product is x_part * 1 or zero and the three parts of a value sum back to it without rounding, so
+    out[:, j] = x[:, perm[j]] must hold EXACTLY -- checked on every row of the big-tile launch and the tail launch
+    (N = 2304) and of the small-tile-only rule (N = 768), for fp32 rows and for planes out."""
+    M, K = 100864, 768
+    rng = np.random.default_rng(5)
+    x = oracle.synth_fill(M * K, 1234, 2.0, 0.3).reshape(M, K)
+    d_x, d_x3 = _dev(pkg, x), _planes_buf(pkg, M, K)
+    _launch(pkg, "vh_launch_split3_rows", None, d_x.ptr, d_x3.ptr, M, K)
+    for N in (768, 2304):
+        perm = rng.integers(0, K, N)
+        w = np.zeros((N, K), np.float32)
+        w[np.arange(N), perm] = 1.0
+        b = np.zeros(N, np.float32)
+        d_w, d_w3, d_b = _dev(pkg, w), _planes_buf(pkg, N, K), _dev(pkg, b)
+        _launch(pkg, "vh_launch_split3_rows", None, d_w.ptr, d_w3.ptr, N, K)
+        want = x[:, perm]
+        d_o = pkg.DeviceBuffer(M * N)
+        _launch(pkg, "vh_launch_linear_p3", None, d_o.ptr, 0, d_w3.ptr, d_x3.ptr, d_b.ptr, M, K, N, 0, None)
+        assert np.array_equal(d_o.to_numpy((M, N)), want), f"fp32 rows out, N={N}"
+        d_o3 = _planes_buf(pkg, M, N)
+        _launch(pkg, "vh_launch_linear_p3", None, d_o3.ptr, 1, d_w3.ptr, d_x3.ptr, d_b.ptr, M, K, N, 0, None)
+        parts = _planes_to_parts(d_o3, M, N)
+        assert np.array_equal((parts[0] + parts[1]) + parts[2], want), f"planes out, N={N}"
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp8"])
 def test_reduced_modes_at_batch_512_are_batch_position_independent(pkg, device, weights, precision):
     """BASELINE config 3's size in its own precision (and the fp8 mode): big-tile launches, tail launches and the
