@@ -6,7 +6,7 @@
  * link against this library unchanged:
  *   ImageData  <- reference MulticoreMainProject/Network.h:7-14
  *   Network    <- reference MulticoreMainProject/Network.h:19-23
- * (tests/test_abi.py checks sizeof/offsetof against the reference header when
+ * (tests/test_host.py checks sizeof/offsetof against the reference header when
  * /root/reference is present, and against the hard numbers below otherwise.)
  *
  * Unlike the reference header this one defines no globals (the reference

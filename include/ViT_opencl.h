@@ -58,6 +58,9 @@ size_t vit_config_tensor_size(const vit_config *cfg, int idx);
  * $VIT_HIP_DEVICE (default 0).  On any device error: message + exit(EXIT_FAILURE),
  * mirroring CHECK_ERROR. */
 void ViT_opencl(ImageData *image, Network *networks, float **probabilities);
+/* Wall-clock split of the calling thread's last ViT_opencl(): context creation -- what the reference prints as
+ * "setup time" (ViT_opencl.c:910) and what Main.c:51-57 times together with the images -- and the rest of the call. */
+void vit_hip_last_call_seconds(double *setup_s, double *forward_s);
 
 /* ---- extended API: resident weights, other configs, logits ---- */
 

@@ -34,3 +34,26 @@ def test_sharded_gather_over_gloo(tmp_path, world, total):
     assert res["ok"] and res["rows"] == total and res["world"] == world
     assert res["slowest"] == float(world)            # max over ranks of (1 + rank)
     assert sum(res["counts"]) == total
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_launch_themselves_verify_the_gather_and_report_the_cpu_baseline():
+    """bench.py's own N > 1 body on the test box's single card: `python bench.py --gpus 2` with no launcher in the
+    environment starts its two ranks itself (torch.distributed.run as a child of a process that never touches the
+    GPU), both pinned to device 0 with the gather over gloo (RCCL refuses two ranks on one GPU; the RCCL group of one
+    is covered by test_rccl_gather_is_ordered_after_the_forward).  The line must carry the rank count, the bitwise
+    verification of the other rank's gathered rows, the CPU baseline and the parity block -- everything the N = 1 line has."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VIT_DIST_BACKEND="gloo", VIT_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "64", "--cpu-procs", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 128
+    assert out["gather"]["gathered_rows_verified"] == 1 and out["gather"]["backend"] == "gloo"
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["roofline"]["frac"] > 0
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] in ("reference", "port")
+    assert out["parity"]["max_abs_dlogit_vs_ViT_seq"] <= 1e-4 and out["parity"]["argmax_equal"]
+    assert out["checks"]["logits_finite"]

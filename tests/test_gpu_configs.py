@@ -1,0 +1,169 @@
+"""BASELINE configs 4 and 5 -- ViT-L/16 with bf16 GEMM operands, ViT-H/14 with block-scaled fp8
+operands -- checked IN THEIR OWN PRECISION against the CPU port, and at their per-GPU batch sizes
+(256 and 512 images) for batch-position independence, bit for bit.
+
+"Parity unpinned" throughout: the reference hard-codes ViT-B/16 (ViT_seq.c:10-21) and has neither
+of these shapes nor reduced-precision arithmetic, so the checker is the port with other loop
+bounds (bit-identical to the reference's own ViT_seq.c on ViT-B/16, tests/test_oracle.py):
+live for the first three layers' residual stream, and through the committed full-depth vectors
+tests/golden/{h14,l16}_port_logits.npz (oracle/make_golden_port.py; 1-2 min of CPU per image).
+Tolerances are the measured errors plus margin, stated where they are asserted.
+"""
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+H14_SEED, H14_FIRST = 3, 5      # weights seed_base / first synthetic image of the ViT-H/14 vectors
+L16_SEED, L16_FIRST = 7, 3
+
+
+@pytest.fixture(scope="module")
+def h14(pkg):
+    cfg = pkg.preset("vit_h_14")
+    return cfg, pkg.synth_weights(cfg, H14_SEED)
+
+
+@pytest.fixture(scope="module")
+def l16(pkg):
+    cfg = pkg.preset("vit_l_16")
+    return cfg, pkg.synth_weights(cfg, L16_SEED)
+
+
+def _rel_l2(got, want):
+    return float(np.linalg.norm(got.astype(np.float64) - want) / np.linalg.norm(want.astype(np.float64)))
+
+
+def _logit_rel_l2(got, want):
+    """error of a logit vector relative to the spread of the reference logits (the mean carries no class information)"""
+    return float(np.linalg.norm(got - want) / np.linalg.norm(want - want.mean()))
+
+
+def _clear_top1(got, want, factor=4.0):
+    """arg-max must agree where the port's top-2 margin exceeds `factor` x the logit error"""
+    top2 = np.sort(want)[-2:]
+    return (top2[1] - top2[0]) <= factor * np.abs(got - want).max() or int(got.argmax()) == int(want.argmax())
+
+
+def test_vit_h14_three_layer_residual_stream_of_every_precision_vs_port(pkg, device, h14):
+    """ViT-H/14 (patch 14, T = 257, E = 1280, 16 heads of 80, F = 5120): the residual stream after three
+    encoder layers of two images -- gathered-rows patch embedding, streaming / resident-fp16 attention, the
+    planes and MX GEMMs -- against the port's (port_forward_image, stop_after_layers = 3; ~10 s of CPU per image),
+    for the fp32 path AND, directly against the same port tokens, the bf16-operand and block-scaled-fp8 modes."""
+    from oracle.oracle import Oracle
+    cfg, weights = h14
+    imgs = pkg.synth_images(cfg, H14_FIRST, 2)
+    orc = Oracle("vit_h_14")
+    with ThreadPoolExecutor(2) as ex:      # the port releases the GIL (ctypes): both images at once
+        want = list(ex.map(lambda i: orc.forward(imgs[i], weights, stop_after_layers=3)[2], range(2)))
+    short = pkg.preset("vit_h_14")
+    short.depth = 3
+    w3 = weights[:4 + 12 * 3] + weights[-4:]
+    got = {}
+    for precision in ("f32", "bf16", "fp8"):
+        m = pkg.ViTHip(short, w3, device=0, max_batch=2, precision=precision)
+        m.forward(imgs)
+        got[precision] = m.read_tokens(2).reshape(2, 257, cfg.embed_dim)
+        m.close()
+    for i in range(2):
+        scale = max(float(np.abs(want[i]).max()), 1.0)
+        err = {p: (float(np.abs(got[p][i] - want[i]).max()) / scale, _rel_l2(got[p][i], want[i])) for p in got}
+        print(f"ViT-H/14 image {H14_FIRST + i}, 3 layers, (max|d|/max|x|, relative L2) vs port:", err)
+        assert err["f32"][0] <= 2e-5, f"fp32 path, image {i}"
+        # bf16 operands: 8 significand bits per GEMM operand, fp32 accumulation and residual stream.
+        # Measured 1.3e-3 (max) / 9e-4 (L2) after three layers; stated bound 4e-3 / 3e-3.
+        assert err["bf16"][0] <= 4e-3 and err["bf16"][1] <= 3e-3, f"bf16 mode, image {i}"
+        # block-scaled e4m3 operands: 4 significand bits, one power-of-two scale per 32 K elements.
+        # Measured 2.6e-2 (max) / 1.7e-2 (L2); stated bound 6e-2 / 4e-2.
+        assert err["fp8"][0] <= 6e-2 and err["fp8"][1] <= 4e-2, f"fp8 mode, image {i}"
+
+
+def test_vit_h14_full_depth_logits_of_every_precision_vs_port_golden(pkg, device, h14):
+    """BASELINE config 5's model at FULL depth (32 layers) against the port's committed logits
+    (tests/golden/h14_port_logits.npz, "port, unpinned"): fp32 path within the north star's 1e-4, the
+    bf16 mode and config 5's own block-scaled fp8 mode at their stated bounds -- against the port, not
+    against this library's fp32 path."""
+    cfg, weights = h14
+    gold = np.load(GOLDEN / "h14_port_logits.npz")
+    assert list(gold["images"]) == [H14_FIRST, H14_FIRST + 1] and int(gold["seed_base"]) == H14_SEED
+    imgs = pkg.synth_images(cfg, H14_FIRST, 2)
+    out = {}
+    for precision in ("f32", "bf16", "fp8"):
+        m = pkg.ViTHip(cfg, weights, device=0, max_batch=2, precision=precision)
+        out[precision] = m.forward(imgs)
+        m.close()
+    for i in range(2):
+        want_l, want_p = gold["logits"][i], gold["probs"][i]
+        l32, p32 = out["f32"][0][i], out["f32"][1][i]
+        assert np.abs(l32 - want_l).max() <= 1e-4 and int(l32.argmax()) == int(want_l.argmax())
+        assert np.abs(p32 - want_p).max() <= 1e-6
+        l16, l8 = out["bf16"][0][i], out["fp8"][0][i]
+        e16, e8 = float(np.abs(l16 - want_l).max()), float(np.abs(l8 - want_l).max())
+        r16, r8 = _logit_rel_l2(l16, want_l), _logit_rel_l2(l8, want_l)
+        print(f"ViT-H/14 image {H14_FIRST + i}, 32 layers vs port: bf16 max|dlogit| {e16:.3e} relL2 {r16:.3e}; "
+              f"fp8 max|dlogit| {e8:.3e} relL2 {r8:.3e}")
+        assert np.isfinite(l16).all() and np.isfinite(l8).all()
+        # bf16 mode, 32 layers: measured 1.6e-2 / 0.6 %; bound 6e-2 (ViT-L/16's 24 layers are held to 6e-2 too)
+        assert e16 <= 6e-2 and r16 <= 2e-2 and _clear_top1(l16, want_l)
+        # fp8 mode (config 5's precision), 32 layers: measured relative L2 0.10-0.12; bound 0.18 (round 2 asserted
+        # 0.25 against this library's own fp32 path)
+        assert r8 <= 0.18 and _clear_top1(l8, want_l)
+        assert abs(float(out["fp8"][1][i].sum()) - 1.0) < 1e-5
+
+
+def test_vit_l16_full_depth_logits_of_both_precisions_vs_port_golden(pkg, device, l16):
+    """BASELINE config 4's model (ViT-L/16, 24 layers) on two images against the port's committed logits: fp32 path
+    within 1e-4; config 4's own precision (bf16 GEMM operands) within 6e-2, probabilities within 3e-4."""
+    cfg, weights = l16
+    gold = np.load(GOLDEN / "l16_port_logits.npz")
+    assert list(gold["images"]) == [L16_FIRST, L16_FIRST + 1] and int(gold["seed_base"]) == L16_SEED
+    imgs = pkg.synth_images(cfg, L16_FIRST, 2)
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=2)
+    l32, p32 = m.forward(imgs)
+    m.close()
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=2, precision="bf16")
+    l16_, p16 = m.forward(imgs)
+    m.close()
+    for i in range(2):
+        want_l, want_p = gold["logits"][i], gold["probs"][i]
+        assert np.abs(l32[i] - want_l).max() <= 1e-4 and int(l32[i].argmax()) == int(want_l.argmax())
+        assert np.abs(p32[i] - want_p).max() <= 1e-6
+        e16 = float(np.abs(l16_[i] - want_l).max())
+        print(f"ViT-L/16 image {L16_FIRST + i}, 24 layers, bf16 mode vs port: max|dlogit| {e16:.3e}")
+        assert e16 <= 6e-2 and np.abs(p16[i] - want_p).max() <= 3e-4 and _clear_top1(l16_[i], want_l, 2.0)
+
+
+def test_vit_h14_fp8_at_512_images_is_batch_position_independent(pkg, device, h14):
+    """BASELINE config 5's per-GPU batch in its own precision: 512 x ViT-H/14, block-scaled fp8 (M = 131 584 rows).
+    Images at the start, the middle and on the hand-over from the big-tile launches to the tail launches (row
+    131 072 = image 510 for every projection's 256-row tiling) get, bit for bit, the logits they get eight at a time."""
+    cfg, weights = h14
+    imgs = pkg.synth_images(cfg, 0, 512)
+    big = pkg.ViTHip(cfg, weights, device=0, max_batch=512, precision="fp8")
+    lb, pb = big.forward(imgs)
+    big.close()
+    pick = [0, 1, 255, 256, 509, 510, 511, 300]
+    small = pkg.ViTHip(cfg, weights, device=0, max_batch=8, precision="fp8")
+    ls, ps = small.forward(imgs[pick])
+    small.close()
+    assert np.isfinite(lb).all() and np.abs(pb.sum(axis=1) - 1.0).max() < 1e-5
+    assert np.array_equal(lb[pick], ls) and np.array_equal(pb[pick], ps)
+
+
+def test_vit_l16_bf16_at_256_images_is_batch_position_independent(pkg, device, l16):
+    """BASELINE config 4's per-GPU batch in its own precision: 256 x ViT-L/16, bf16 operands (M = 50 432 rows; the
+    256x256-tile launches of QKV, fc1 and fc2 hand over to 128x128 tiles at row 49 152 = image 249)."""
+    cfg, weights = l16
+    imgs = pkg.synth_images(cfg, 0, 256)
+    big = pkg.ViTHip(cfg, weights, device=0, max_batch=256, precision="bf16")
+    lb, pb = big.forward(imgs)
+    big.close()
+    pick = [0, 1, 127, 128, 248, 249, 250, 255]
+    small = pkg.ViTHip(cfg, weights, device=0, max_batch=8, precision="bf16")
+    ls, ps = small.forward(imgs[pick])
+    small.close()
+    assert np.isfinite(lb).all() and np.array_equal(lb[pick], ls) and np.array_equal(pb[pick], ps)

@@ -487,83 +487,7 @@ def test_rccl_gather_is_ordered_after_the_forward(tmp_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
 
 
-def test_vit_l16_one_image_vs_oracle(pkg, device):
-    """BASELINE config 4 shape (ViT-L/16: E=1024, 16 heads, F=4096, 24 layers) through the
-    same kernels.  The reference has no code for this shape (ViT_seq.c:10-21 hard-codes
-    B/16), so the oracle here is the port with other loop bounds: "parity unpinned".
-    ~40 s of CPU for the one oracle image."""
-    from oracle.oracle import Oracle
-    orc = Oracle("vit_l_16")
-    cfg = pkg.preset("vit_l_16")
-    weights = pkg.synth_weights(cfg, 7)
-    imgs = pkg.synth_images(cfg, 3, 2)
-    m = pkg.ViTHip(cfg, weights, device=0, max_batch=2)
-    logits, probs = m.forward(imgs)
-    m.close()
-    want_logits, want_probs, _ = orc.forward(imgs[1], weights)
-    assert np.abs(logits[1] - want_logits).max() <= LOGIT_TOL
-    assert int(logits[1].argmax()) == int(want_logits.argmax())
-    assert np.abs(probs[1] - want_probs).max() <= 1e-6
-    # BASELINE config 4 in ITS precision: ViT-L/16 with bf16 GEMM operands (fp32 accumulation, residual
-    # stream, norms and attention statistics).  Stated tolerance: class logits within 6e-2 of the CPU
-    # port (24 layers of 8-bit operands; B/16's 12 layers are held to 4e-2), probabilities within 3e-4,
-    # arg-max equal where the port's top-2 margin exceeds twice the tolerance.  "parity unpinned".
-    m16 = pkg.ViTHip(cfg, weights, device=0, max_batch=2, precision="bf16")
-    l16, p16 = m16.forward(imgs)
-    m16.close()
-    d16 = float(np.abs(l16[1] - want_logits).max())
-    print("ViT-L/16 bf16 mode: max |dlogit| vs port", d16, "vs fp32 path", float(np.abs(l16 - logits).max()))
-    assert np.isfinite(l16).all() and d16 <= 6e-2
-    assert np.abs(p16[1] - want_probs).max() <= 3e-4
-    srt = np.sort(want_logits)
-    if srt[-1] - srt[-2] > 1.2e-1:
-        assert int(l16[1].argmax()) == int(want_logits.argmax())
-    assert np.abs(l16[0] - logits[0]).max() <= 6e-2          # image 0: against the fp32 path (itself checked above)
-
-
-def test_vit_h14_layers_vs_oracle(pkg, device):
-    """BASELINE config 5 shape (ViT-H/14: patch 14, T = 257, E = 1280, 16 heads of 80, F = 5120)
-    through the gathered-rows patch embedding, the streaming attention kernel and the GEMMs.
-    The full 32-layer oracle image costs ~2 min of CPU, so the residual stream is compared
-    after 3 layers (port_forward_image's stop_after_layers) for two images, fp32 path, and
-    the bf16-operand mode runs the whole model for finiteness and agreement with fp32."""
-    from oracle.oracle import Oracle
-    orc = Oracle("vit_h_14")
-    cfg = pkg.preset("vit_h_14")
-    weights = pkg.synth_weights(cfg, 3)
-    imgs = pkg.synth_images(cfg, 5, 2)
-    m = pkg.ViTHip(cfg, weights, device=0, max_batch=2)
-    logits, probs = m.forward(imgs)
-    assert np.isfinite(logits).all() and np.abs(probs.sum(axis=1) - 1).max() < 1e-5
-    m.close()
-    short = pkg.preset("vit_h_14")
-    short.depth = 3
-    m3 = pkg.ViTHip(short, weights[:4 + 12 * 3] + weights[-4:], device=0, max_batch=2)
-    m3.forward(imgs)
-    toks = m3.read_tokens(2).reshape(2, 257, cfg.embed_dim)
-    m3.close()
-    for i in range(2):
-        _, _, want = orc.forward(imgs[i], weights, stop_after_layers=3)
-        assert np.abs(toks[i] - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0), f"image {i}"
-    m16 = pkg.ViTHip(cfg, weights, device=0, max_batch=2, precision="bf16")
-    l16, _ = m16.forward(imgs)
-    m16.close()
-    assert np.isfinite(l16).all() and np.abs(l16 - logits).max() <= 8e-2
-    # BASELINE config 5 in ITS precision: ViT-H/14 with block-scaled e4m3 GEMM operands (MX: one power-of-two
-    # scale per 32 K elements, no calibration; csrc/gemm_mx.hip), against the fp32 path of this same test
-    # (itself checked against the port after 3 layers above).  Same statement of tolerance as the B/16 fp8
-    # test: relative L2 error of the logit vector, and top-1 where the margin is clear.
-    # "parity unpinned" (the reference has no H/14 and no fp8).
-    m8 = pkg.ViTHip(cfg, weights, device=0, max_batch=2, precision="fp8")
-    l8, p8 = m8.forward(imgs)
-    m8.close()
-    rel = np.linalg.norm(l8 - logits, axis=1) / np.linalg.norm(logits - logits.mean(axis=1, keepdims=True), axis=1)
-    print("ViT-H/14 fp8 mode: relative L2 logit error per image:", rel, "max |dlogit|", float(np.abs(l8 - logits).max()))
-    assert np.isfinite(l8).all() and np.abs(p8.sum(axis=1) - 1).max() < 1e-5
-    assert rel.max() <= 0.25
-    top2 = np.sort(logits, axis=1)[:, -2:]
-    clear = (top2[:, 1] - top2[:, 0]) > 4 * np.abs(l8 - logits).max(axis=1)
-    assert (l8.argmax(1) == logits.argmax(1))[clear].all()
+# ViT-L/16 and ViT-H/14 (BASELINE configs 4 and 5), in every precision and at their per-GPU batches: tests/test_gpu_configs.py
 
 
 # torchvision state-dict key of tensor idx (reference file names: Network/Weight_<idx>_<key>.bin)

@@ -4,9 +4,15 @@ rows [0, 98304) + 128x128-tile launch over the rest) of the default fp32 path, c
 Usage: pmc_traffic.py <summary.txt> > profiles/r02_pmc_traffic.json
 Corrections as MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports half the bytes of wide coalesced reads."""
+import hashlib
 import json
 import re
+import subprocess
 import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+KERNEL_SOURCE = ROOT / "vit-with-opencl_amd" / "csrc" / "gemm_p3.hip"
 
 M, N, K, SPLIT_ROW = 100864, 3072, 768, 98304
 
@@ -29,12 +35,20 @@ def main(path):
     tail = b[("gemm_p3_kernel<4, 128, 1, 1, 3, 0>", ((M - SPLIT_ROW) // 128) * (N // 128) * 256)]
     fetch, write = big["FETCH_SIZE"] + tail["FETCH_SIZE"], big["WRITE_SIZE"] + tail["WRITE_SIZE"]
     alg = (M * (K + N) + N * K) * 6
+    try:
+        head = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
     out = {
+        # what the figures were measured on: bench.py withholds `traffic` when the kernel source has changed since
+        "kernel_source": "vit-with-opencl_amd/csrc/gemm_p3.hip",
+        "kernel_source_sha256": hashlib.sha256(KERNEL_SOURCE.read_bytes()).hexdigest(),
+        "git_head": head or None,
         "kernel": "fc1 = gemm_p3_kernel<8,256,EPI_GELU,OUT_PLANES,NPL=3> on rows [0, 98304) + gemm_p3_kernel<4,128,...> "
                   "for the last 2560 rows (M=100864 N=3072 K=768); counters of the two launches added",
         "source": "rocprofv3 --kernel-trace --output-format csv, separate --pmc passes (tools/pmc_passes.sh) on `python3 "
                   "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end`; per-dispatch means in "
-                  "profiles/r02_pmc_summary.txt; this file by tools/pmc_traffic.py",
+                  "the round's profiles/rNN_pmc_summary.txt; this file by tools/pmc_traffic.py",
         "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
         "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of wide "
                       "coalesced reads (MI355X_MICROARCH.md, HBM); the counters sit on the L2's memory side, so "

@@ -207,7 +207,10 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
                       int n_tensors, int device, int max_batch, int precision)
 {
     int rc = 0;
-    if (!out || !cfg || !networks || max_batch <= 0)
+    if (!out)
+        return 1;
+    *out = NULL;
+    if (!cfg || !networks || max_batch <= 0)
         return 1;
     if (precision != VIT_PRECISION_F32 && precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM &&
         precision != VIT_PRECISION_F32_FP16X2)
@@ -218,7 +221,6 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
         return 2;
     if (precision == VIT_PRECISION_BF16_GEMM && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
         return 2;
-    *out = NULL;
     if (n_tensors != vit_config_num_tensors(cfg))
         return 2;
     if (cfg->embed_dim % cfg->num_heads != 0 || cfg->img_size % cfg->patch_size != 0)
@@ -958,6 +960,17 @@ static int parse_devices(const char *env, int *out, int capacity)
     return n;
 }
 
+/* Wall-clock split of the calling thread's last ViT_opencl(): context creation (the reference's "setup time",
+ * ViT_opencl.c:910) and everything after it up to the return (forward + teardown). */
+static _Thread_local double last_setup_s, last_forward_s;
+void vit_hip_last_call_seconds(double *setup_s, double *forward_s)
+{
+    if (setup_s)
+        *setup_s = last_setup_s;
+    if (forward_s)
+        *forward_s = last_forward_s;
+}
+
 /* The drop-in entry point (reference ViT_opencl.c:794).  Same observable
  * behaviour: fills probabilities[i][0..999]; prints a setup-time line and a
  * throughput line where the reference prints "setup time" / "picture #i". */
@@ -998,6 +1011,8 @@ void ViT_opencl(ImageData *image, Network *networks, float **probabilities)
         printf("pictures #0..#%d: %.6f sec (%.1f images/sec)\n\n", n - 1, t2m - t1m,
                (double)n / (t2m - t1m > 0 ? t2m - t1m : 1e-9));
         vit_hip_destroy_multi(m);
+        last_setup_s = t1m - t0;
+        last_forward_s = wall_seconds() - t1m;
         return;
     }
     if (n_devices == 1)
@@ -1016,4 +1031,6 @@ void ViT_opencl(ImageData *image, Network *networks, float **probabilities)
     printf("pictures #0..#%d: %.6f sec (%.1f images/sec)\n\n", n - 1, t2 - t1,
            (double)n / (t2 - t1 > 0 ? t2 - t1 : 1e-9));
     vit_hip_destroy(ctx);
+    last_setup_s = t1 - t0;
+    last_forward_s = wall_seconds() - t1;
 }

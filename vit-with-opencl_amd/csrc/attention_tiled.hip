@@ -98,8 +98,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_tiled_kernel(const float
         }
     }
 
-    /* Two chunks are in flight in registers: a chunk's MFMAs take a few hundred cycles, its global loads one to two
-     * microseconds -- with one chunk ahead the loop ran at the load latency (18 chunk steps of ~2 us per workgroup). */
+    /* One chunk is in flight in registers, one step ahead of the chunk being consumed: a chunk's MFMAs take a few hundred
+     * cycles, its global loads one to two microseconds.  (Two chunks in flight were tried: the compiler still places the
+     * loads one step ahead, no effect -- DESIGN 5.) */
     f32x4 stage[1][PPT];
     /* piece p of a chunk = 16 bytes; threads past the last piece repeat it (same bytes to the same LDS address): a
      * per-thread condition here becomes a branch on EXEC, and at its join the compiler drains every load in flight */

@@ -654,6 +654,7 @@ using Tile3 = Tile<256, 256, 2, 4>; /*  8 waves of 128x64 */
 using Tile4 = Tile<256, 256, 4, 4>; /* 16 waves of 64x64: native fp32 */
 using Tile8 = Tile<256, 256, 4, 2>; /*  8 waves of 64x128 (pre-split weights: fewer A splits per wave) */
 using Tile9 = Tile<128, 128, 4, 1>; /*  4 waves of 32x128, 2 workgroups per CU */
+using TileS = Tile<32, 64, 1, 2>;   /*  2 waves of 32x32: skinny problems (the classifier at batch <= 512) */
 
 /* fp32 products: the exact 3-way bf16 split on the bf16 cores (default), or the native
  * fp32 MFMA (VIT_HIP_GEMM_FP32=native).  Both give fp32-level results (same measured
@@ -679,8 +680,14 @@ template <int AMODE, int EPI>
 int launch(hipStream_t st, const GemmParams &p)
 {
     const bool big = p.N % 256 == 0 && p.M >= 4096 && !(EPI == EPI_RESID && p.K < 2048);
-    if (p.N % 128 != 0)                      /* ragged N: only the guarded 128x128 tile */
+    if (p.N % 128 != 0) {                    /* ragged N (the classifier): the guarded tiles on the native fp32 MFMA */
+        /* a skinny problem (M = batch, N = 1000: 32 tiles of 128x128 on 256 CUs, 53 us) goes to 32x64 tiles,
+         * one 32x32 block per wave -- 256 workgroups for 512 x 1000, same k order, same bits */
+        const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        if (2 * tiles128 < vh_device_cus(vh_current_device()))
+            return launch_tile<TileS, AMODE, EPI, true>(st, p);
         return launch_tile<Tile0, AMODE, EPI, true>(st, p);
+    }
     if (use_split3() && aligned16(p))
         return big ? launch_mf16<Tile3, AMODE, EPI, K_F32, K_F32, true>(st, p)
                    : launch_mf16<Tile1, AMODE, EPI, K_F32, K_F32, true>(st, p);

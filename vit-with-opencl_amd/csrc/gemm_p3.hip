@@ -85,7 +85,7 @@ template <int NW, int BN, int EPI, int OUTK, int NPL = 3, int LAB = 0>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
 {
     constexpr int BM = 32 * NW, JT = BN / 16;
-    constexpr int KG = NPL == 3 ? 1 : 2;       /* 32-deep K groups per LDS stage */
+    constexpr int KG = NPL == 3 ? 1 : P1_KG;   /* 32-deep K groups per LDS stage (the launcher sizes the LDS from the same macro) */
     constexpr int RING = NPL == 3 ? 2 : 4;          /* W fragments in flight in registers */
     constexpr int F = KG * JT;                      /* W fragments per step */
     constexpr int NT = NPL == 3 ? 6 : 1;            /* products per block */

@@ -61,14 +61,18 @@ int vh_init(int device)
     }
     if (device < 0 || device >= n)
         return vh_fail(101, "vh_init: device %d out of range (0..%d)", device, n - 1);
+    if (device >= VH_MAX_DEVICES)
+        return vh_fail(101, "vh_init: device %d is beyond the %d devices this library keeps launch state for", device,
+                       VH_MAX_DEVICES);
     VH_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     VH_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return vh_fail(102, "vh_init: device %d is %s; the kernels in this library are built for gfx950 only",
                        device, prop.gcnArchName);
-    snprintf(g_devname, sizeof(g_devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
-             prop.multiProcessorCount);
+    /* some driver stacks (no amdgpu.ids file) report an empty marketing name */
+    snprintf(g_devname, sizeof(g_devname), "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct accelerator",
+             prop.gcnArchName, prop.multiProcessorCount);
     return 0;
 }
 

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -48,7 +49,9 @@ int vh_attention_tiled(void *stream, const float *qkv, void *output, int out_bf1
 
 /* Launch state that is per DEVICE (a process may hold contexts on several GPUs, one host thread each):
  * hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are cached per device id. */
-#define VH_MAX_DEVICES 16
+/* The caches are atomics: several host threads (one per device, or several contexts on one device) may fill a slot at
+ * the same time; filling it twice is harmless, a torn read is not.  vh_init refuses device ids >= VH_MAX_DEVICES. */
+#define VH_MAX_DEVICES 64
 static inline int vh_current_device(void)
 {
     int dev = 0;
@@ -58,27 +61,27 @@ static inline int vh_current_device(void)
 }
 static inline int vh_device_cus(int dev)
 {
-    static int cus[VH_MAX_DEVICES];
+    static std::atomic<int> cus[VH_MAX_DEVICES];
     if (dev < 0 || dev >= VH_MAX_DEVICES)
         return 256;
-    if (cus[dev] == 0) {
-        int n = 0;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;
-        cus[dev] = n;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
-    return cus[dev];
+    return n;
 }
 /* once per (kernel instantiation, device): raise the dynamic-LDS limit of `func` to `bytes` */
 #define VH_SET_LDS_ONCE(func, bytes)                                                         \
     do {                                                                                     \
-        static bool vh_attr_set_[VH_MAX_DEVICES];                                            \
+        static std::atomic<bool> vh_attr_set_[VH_MAX_DEVICES];                               \
         const int vh_dev_ = vh_current_device();                                             \
         if (vh_dev_ < 0)                                                                     \
             return vh_fail(1, "no current HIP device (or device id >= %d)", VH_MAX_DEVICES); \
-        if (!vh_attr_set_[vh_dev_]) {                                                        \
+        if (!vh_attr_set_[vh_dev_].load(std::memory_order_acquire)) {                        \
             VH_TRY(hipFuncSetAttribute((const void *)(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
-            vh_attr_set_[vh_dev_] = true;                                                    \
+            vh_attr_set_[vh_dev_].store(true, std::memory_order_release);                    \
         }                                                                                    \
     } while (0)
 

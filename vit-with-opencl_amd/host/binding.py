@@ -31,7 +31,7 @@ EXPORTS = [
     "vh_launch_patch_embed", "vh_launch_layer_norm", "vh_launch_linear", "vh_launch_attention",
     "vh_launch_softmax",
     "vit_config_preset", "vit_config_tokens", "vit_config_num_tensors", "vit_config_tensor_size",
-    "ViT_opencl", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
+    "ViT_opencl", "vit_hip_last_call_seconds", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
     "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_profile_select", "vit_hip_create_ex", "vit_hip_precision",
     "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_launch_split3_planes", "vh_launch_linear_w3",
@@ -184,6 +184,8 @@ def lib() -> C.CDLL:
     L.vit_config_tensor_size.restype = sz
     L.ViT_opencl.argtypes = [C.POINTER(ImageData), C.POINTER(Network), C.POINTER(f32p)]
     L.ViT_opencl.restype = None
+    L.vit_hip_last_call_seconds.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.vit_hip_last_call_seconds.restype = None
     L.vit_hip_create.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i]
     L.vit_hip_create_ex.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i, i]
     L.vit_hip_precision.argtypes = [voidp]
