@@ -99,6 +99,19 @@ int vh_launch_patch_embed_ws(vh_stream_t s, const float *images, const float *co
                              float *tokens, int n_images, int in_chans, int img_size,
                              int patch_size, int embed_dim, void *workspace, size_t workspace_bytes);
 
+/* The patch embedding of the reduced-precision modes (bf16 / fp8 GEMM operands; conv2d.cl:1-80 for them): an im2row
+ * producer writes the patches as one-part bf16 planes [Kp/32][1][n_images*grid^2][32] into `workspace` (Kp =
+ * vh_patch_planes_k(): in_chans*patch^2 padded with zeros to the one-part K step; Kp * 2 bytes per patch row), and
+ * the planes GEMM (vh_launch_linear_planes, parts = 1) runs with a token-row epilogue.  `conv_w_planes` =
+ * [Kp/32][1][embed][32], written once by vh_launch_conv_weight_planes.  fp32 accumulation, bias, position
+ * embedding and class-token rows as vh_launch_patch_embed; pixels and weights are rounded to bf16.  embed % 128 == 0. */
+int vh_patch_planes_k(int in_chans, int patch_size);
+int vh_launch_conv_weight_planes(vh_stream_t s, const float *conv_w, void *planes, int embed_dim, int in_chans, int patch_size);
+int vh_launch_patch_embed_planes(vh_stream_t s, const float *images, const void *conv_w_planes, const float *conv_b,
+                                 const float *cls_token, const float *pos_embed, float *tokens, int n_images,
+                                 int in_chans, int img_size, int patch_size, int embed_dim, void *workspace,
+                                 size_t workspace_bytes);
+
 /* Row LayerNorm, y = (x-mean)*inv_std*w + b with var = E[x^2]-mean^2 and
  * inv_std = 1/sqrt(var+eps) (eps added in double, ViT_seq.c:21,135).
  * Replaces layer_norm (ViT_opencl.c:444-482; layerNorm layer_norm.cl:3; CPU

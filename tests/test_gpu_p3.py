@@ -476,3 +476,37 @@ def test_last_layer_on_class_token_rows_only_gives_identical_logits(pkg, device,
     assert np.array_equal(cls_l, full_l) and np.array_equal(cls_p, full_p) and np.array_equal(again_l, full_l)
     assert np.array_equal(one_l[0], full_l[3])
     assert np.abs(full_l[:4] - golden_full["logits"][:4]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("preset,n", [("vit_b_16", 3), ("vit_h_14", 2), ("vit_b_16", 30)])
+def test_patch_embed_on_one_part_planes_vs_oracle_on_bf16_rounded_operands(pkg, device, preset, n):
+    """vh_launch_patch_embed_planes -- the reduced modes' conv_proj (conv2d.cl:1-80): im2row producer writing one-part
+    bf16 planes, planes GEMM with the token-row epilogue.  The port's conv loop (ViT_seq.c:25-57 restated) on the SAME
+    bf16-rounded pixels and weights differs by summation order only: the fp32 operator tolerance applies.  ViT-H/14's
+    patch 14 (K = 588, padded to 640 with zeros) takes the element-wise gather; 30 images of ViT-B/16 (M = 5880) run
+    several 128x128 tiles and a ragged last one."""
+    from oracle.oracle import Oracle
+    orc = Oracle(preset)
+    cfg = pkg.preset(preset)
+    E, T, P = cfg.embed_dim, pkg.binding.tokens(cfg), cfg.patch_size
+    W = [orc.synth_fill(orc.tensor_size(i), 40 + i, 0.05, 0.0) for i in range(4)]
+    imgs = pkg.synth_images(cfg, 20, n)
+    L = pkg.lib()
+    Kp = L.vh_patch_planes_k(3, P)
+    assert Kp == (768 if P == 16 else 640)
+    d = [_dev(pkg, a) for a in (imgs, W[1], W[2], W[0], W[3])]
+    d_wp = pkg.DeviceBuffer(E * Kp // 2)
+    _launch(pkg, "vh_launch_conv_weight_planes", None, d[1].ptr, d_wp.ptr, E, 3, P)
+    wr = _planes1_to_f32(d_wp, E, Kp)
+    K = 3 * P * P
+    assert np.array_equal(wr[:, :K], _bf16_rne(W[1]).reshape(E, K)) and not wr[:, K:].any()
+    need = n * (T - 1) * Kp * 2
+    d_ws, d_tok = pkg.DeviceBuffer(need // 4), pkg.DeviceBuffer(n * T * E)
+    assert L.vh_launch_patch_embed_planes(None, d[0].ptr, d_wp.ptr, d[2].ptr, d[3].ptr, d[4].ptr, d_tok.ptr, n, 3, 224, P, E,
+                                          d_ws.ptr, need - 16) != 0          # workspace too small
+    _launch(pkg, "vh_launch_patch_embed_planes", None, d[0].ptr, d_wp.ptr, d[2].ptr, d[3].ptr, d[4].ptr, d_tok.ptr, n, 3, 224, P, E,
+            d_ws.ptr, need)
+    got = d_tok.to_numpy((n, T, E))
+    for i in sorted({0, n // 2, n - 1}):
+        want = orc.tokens_from_conv(orc.conv2d(_bf16_rne(imgs[i]), _bf16_rne(W[1]), W[2]), W[0], W[3])
+        assert np.abs(got[i] - want).max() <= OP_TOL, f"image {i}"

@@ -59,6 +59,8 @@ struct vit_hip_ctx
     /* FP8_GEMM: block-scaled e4m3 copies of the same four matrices (values, then their e8m0 block scales) */
     void *w8_slab;
     void **w8, **w8s;   /* per tensor index: values, scales */
+    /* BF16_GEMM / FP8_GEMM: conv_proj as one-part bf16 planes [Kp/32][1][E][32] (vh_launch_patch_embed_planes) */
+    void *wconv16;
 
     /* activation arena (rows = max_batch * tokens) */
     float *x;           /* residual stream      [rows][E]   */
@@ -161,6 +163,8 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
     free(ctx->w3_scale);
     if (ctx->w8_slab)
         vh_free(ctx->w8_slab);
+    if (ctx->wconv16)
+        vh_free(ctx->wconv16);
     free(ctx->w8);
     free(ctx->w8s);
     float *dev[] = {ctx->w_slab, ctx->x, ctx->y, ctx->attn, ctx->qkv, ctx->hid,
@@ -377,6 +381,13 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
             }
     }
 
+    if ((precision == VIT_PRECISION_BF16_GEMM || precision == VIT_PRECISION_FP8_GEMM) && cfg->embed_dim % 128 == 0) {
+        /* the reduced modes' patch embedding: conv weights rounded to bf16 planes, K padded to the one-part K step */
+        const size_t kp = (size_t)vh_patch_planes_k(cfg->in_chans, cfg->patch_size);
+        TRY(vh_malloc(&ctx->wconv16, kp * (size_t)cfg->embed_dim * 2));
+        TRY(vh_launch_conv_weight_planes(ctx->stream, ctx->w[1], ctx->wconv16, cfg->embed_dim, cfg->in_chans, cfg->patch_size));
+    }
+
     const size_t E = (size_t)cfg->embed_dim, F = (size_t)cfg->mlp_hidden, NC = (size_t)cfg->num_classes;
     const size_t rows = (size_t)max_batch * ctx->tokens;
     const size_t img = (size_t)cfg->in_chans * cfg->img_size * cfg->img_size;
@@ -438,8 +449,12 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     float **w = ctx->w;
 
     /* patch embedding + class token + position embedding (ViT_seq.c:437-443) */
-    OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_ws(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n, c->in_chans,
-                                                    c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
+    if (ctx->wconv16)   /* reduced modes: im2row to one-part planes (in the MLP buffer, idle here) + the planes GEMM */
+        OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_planes(s, d_images, ctx->wconv16, w[2], w[0], w[3], ctx->x, n, c->in_chans,
+                                                            c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
+    else
+        OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_ws(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n, c->in_chans,
+                                                        c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
 
     const int mode = ctx->precision;
     const float *final_x = ctx->x;          /* what the final LayerNorm reads: row i * final_stride is image i's class token */

@@ -75,4 +75,36 @@ __device__ __forceinline__ f32x2 gelu_exact2(f32x2 x)
     return (x * 0.5f) * (k(1.0f) + erf_a);
 }
 
+/* GELU for epilogues whose output is ROUNDED to bf16 (KIND 0: 8 significand bits) or to e4m3 (KIND 1: 4 bits) -- the
+ * reduced modes' fc1.  The same form with S of a degree matched to the output format (tools/fit_gelu_lowp.py: degree 4
+ * on [0, 3.5], error <= 0.18 of a bf16 rounding step; degree 3 on [0, 3], <= 0.03 of an e4m3 step; absolute error
+ * <= 1.8e-5 / 1.1e-4) and the final algebra folded:
+ *     gelu(x) = 0.5 x (1 + sign(a)(1 - e)) = max(x, 0) - 0.5 |x| e,   e = 2^(-t S(t)), t = min(|x| / sqrt 2, c)
+ * 6 (5) packed multiply-adds less per pair than gelu_exact2.  The fp32 paths never use it. */
+template <int KIND>
+__device__ __forceinline__ f32x2 gelu_lowp2(f32x2 x)
+{
+    auto k = [](float c) { return f32x2{c, c}; };
+    const f32x2 a = x * 0.70710678118654752f;
+    const float clamp = KIND == 0 ? 3.5f : 3.0f;
+    const f32x2 t = __builtin_elementwise_min(__builtin_elementwise_abs(a), k(clamp));
+    f32x2 s;
+    if (KIND == 0) {
+        s = k(1.978939632e-03f);
+        s = __builtin_elementwise_fma(s, t, k(-2.493243292e-02f));
+        s = __builtin_elementwise_fma(s, t, k(1.416560262e-01f));
+        s = __builtin_elementwise_fma(s, t, k(9.218431711e-01f));
+        s = __builtin_elementwise_fma(s, t, k(1.627655268e+00f));
+    } else {
+        s = k(-1.295685954e-02f);
+        s = __builtin_elementwise_fma(s, t, k(1.189612895e-01f));
+        s = __builtin_elementwise_fma(s, t, k(9.356397390e-01f));
+        s = __builtin_elementwise_fma(s, t, k(1.626340985e+00f));
+    }
+    const f32x2 ts = t * s;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-ts[0]), __builtin_amdgcn_exp2f(-ts[1])};
+    const f32x2 h = (x * 0.5f) * e;
+    return __builtin_elementwise_max(x, k(0.0f)) - __builtin_elementwise_abs(h);
+}
+
 #endif

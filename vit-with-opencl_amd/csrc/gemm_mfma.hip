@@ -946,6 +946,16 @@ bool patch_direct(int in_chans, int img_size, int patch_size)
 
 } // namespace
 
+int vh_cls_rows(hipStream_t st, const float *cls_token, const float *pos_embed, float *tokens, int n_images,
+                int tokens_per_image, int embed_dim)
+{
+    const int total = n_images * embed_dim;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, st, cls_token, pos_embed, tokens, n_images,
+                       tokens_per_image, embed_dim);
+    VH_LAUNCH_CHECK("cls_rows_kernel");
+    return 0;
+}
+
 extern "C" size_t vh_patch_embed_workspace(int n_images, int in_chans, int img_size, int patch_size, int embed_dim)
 {
     if (n_images <= 0 || in_chans <= 0 || img_size <= 0 || patch_size <= 0 || embed_dim <= 0 ||
@@ -982,10 +992,8 @@ extern "C" int vh_launch_patch_embed_ws(vh_stream_t s, const float *images, cons
     p.tokens = grid * grid + 1;
     hipStream_t st = (hipStream_t)s;
 
-    const int total = n_images * embed_dim;
-    hipLaunchKernelGGL(cls_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, st, cls_token,
-                       pos_embed, tokens, n_images, p.tokens, embed_dim);
-    VH_LAUNCH_CHECK("cls_rows_kernel");
+    if (int rc = vh_cls_rows(st, cls_token, pos_embed, tokens, n_images, p.tokens, embed_dim))
+        return rc;
     if (direct)
         return launch<A_PATCH, EPI_PATCH>(st, p);
 

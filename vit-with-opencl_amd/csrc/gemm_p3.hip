@@ -57,7 +57,7 @@ typedef const __attribute__((address_space(1))) f32x4 *gvec_t;
 #ifndef P1_KG
 #define P1_KG 2   /* one-part operands: 32-deep K groups per LDS stage (one barrier per 32 * P1_KG k) */
 #endif
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
 enum { OUT_F32 = 0, OUT_PLANES = 1, OUT_PLANES_H = 2 };   /* _H: one-part planes of fp16 (the reduced modes' Q|K|V) */
 
 struct P3Params {
@@ -70,6 +70,10 @@ struct P3Params {
     int N, K;
     int a_rows;               /* rows of the whole activation matrix = the planes' row count */
     int mtiles, ntiles;
+    /* EPI_PATCH (patch embedding): GEMM row m = patch (m / np, m % np) lands in token row image * tokens + 1 + patch,
+     * plus that token's position embedding (ViT_seq.c:65-80,114-117) */
+    const float *pos;         /* [tokens][N] */
+    int np, tokens;
 };
 
 /* NPL = parts per value: 3 = the exact fp32 split (six products per block, the default fp32 path);
@@ -80,7 +84,8 @@ struct P3Params {
  * the W DMA after the prologue, bit 2 the A loads after the prologue, bit 3 the barrier, bit 4 makes every
  * workgroup load the A rows of tile 0, bit 5 the W rows of tile 0 (operands served by L2 alone), bit 6 drops
  * the epilogue's stores -- throw-away
- * ablations that price each data movement; their results are wrong by construction. */
+ * ablations that price each data movement; their results are wrong by construction; bit 7 keeps the one-part
+ * residual in the epilogue (the form before R_IN_ACC). */
 template <int NW, int BN, int EPI, int OUTK, int NPL = 3, int LAB = 0>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
 {
@@ -118,17 +123,38 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
     const unsigned wlane = (unsigned)(lane >> 2) * 64u + 16u * ((lane & 3) ^ swz64(lane >> 4));
     const gchar_t wtile = (gchar_t)p.W + (size_t)((LAB & 32) ? 0 : n0) * 64;
 
-    /* W fragment j = 2s + b, MFMA row l15 = LDS row 32s + 8*(l15 >> 2) + 4b + (l15 & 3) */
-    const int rl = 8 * (l15 >> 2) + (l15 & 3);
-    const unsigned woff_e = (unsigned)rl * 64u + 16u * (q ^ swz64(2 * (l15 >> 2)));
-    const unsigned woff_o = (unsigned)(rl + 4) * 64u + 16u * (q ^ swz64(2 * (l15 >> 2) + 1));
+    /* W fragment j = 2s + b.  Planes out: MFMA row l15 = LDS row 32s + 8*(l15 >> 2) + 4b + (l15 & 3), so that a lane
+     * ends up with EIGHT consecutive columns (one 16-byte store of 16-bit values per part).  fp32 rows out (NATURAL):
+     * MFMA row l15 = LDS row 32s + 16b + l15 -- a lane holds columns 16j + 4q .. +3 of fragment j and the four lanes of
+     * a row write 64 contiguous bytes per store instruction (with the permuted rows a store instruction writes every
+     * other 16 bytes of a line).  Every output element sums the same products in the same order either way. */
+    constexpr bool NATURAL = OUTK == OUT_F32 && !(LAB & 256);
+    const int rl = NATURAL ? l15 : 8 * (l15 >> 2) + (l15 & 3);
+    const unsigned woff_e = (unsigned)rl * 64u + 16u * (q ^ swz64(NATURAL ? (l15 >> 2) : 2 * (l15 >> 2)));
+    const unsigned woff_o = NATURAL ? woff_e + 16u * 64u
+                                    : (unsigned)(rl + 4) * 64u + 16u * (q ^ swz64(2 * (l15 >> 2) + 1));
+    /* first column (relative to n0) of the four values a lane holds of fragment j */
+    auto frag_col = [&](int j) { return NATURAL ? 16 * j + 4 * q : 32 * (j >> 1) + 8 * q + 4 * (j & 1); };
 
+    /* One-part operands (the reduced modes): the residual goes INTO the accumulators with the bias, (r + bias) + sum
+     * instead of r + (bias + sum) -- its load then runs under the prologue's DMA instead of behind the K loop, costs no
+     * registers, and the epilogue is stores only.  The sums differ in the last bits (every MFMA rounds at the
+     * magnitude of r): far inside what bf16 operands leave, but not the reference's order, so the exact fp32 path
+     * (NPL = 3) keeps adding the residual to the finished sum (ViT_seq.c:350,362). */
+    constexpr bool R_IN_ACC = EPI == EPI_RESID && NPL == 1 && !(LAB & 128);
     f32x4 acc[2][JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + n0 + 32 * (j >> 1) + 8 * q + 4 * (j & 1));
-        acc[0][j] = bv;
-        acc[1][j] = bv;
+        const int col = n0 + frag_col(j);
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + col);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc[i][j] = bv;
+            if (R_IN_ACC) {   /* rows past the end re-read the last row (never stored) */
+                const int row = min(m0 + 32 * wave + 16 * i + l15, p.row_end - 1);
+                acc[i][j] = *reinterpret_cast<const f32x4 *>(p.R + (size_t)row * p.N + col) + bv;
+            }
+        }
     }
 
     frag_t a0[KG][2][NPL], a1[KG][2][NPL], w[RING][NPL];
@@ -234,20 +260,33 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
         const int row = m0 + 32 * wave + 16 * i + l15;
         if (row >= p.row_end)
             continue;
+        size_t orow = (size_t)row;
+        const float *posrow = nullptr;
+        if (EPI == EPI_PATCH) {
+            const int b = row / p.np, pp = row - b * p.np;
+            orow = (size_t)b * p.tokens + 1 + pp;
+            posrow = p.pos + (size_t)(1 + pp) * p.N;
+        }
 #pragma unroll
         for (int s = 0; s < JT / 2; ++s) {
-            const int col = n0 + 32 * s + 8 * q;
+            const int col = n0 + frag_col(2 * s), col_hi = n0 + frag_col(2 * s + 1);   /* planes: col_hi = col + 4 */
             f32x4 lo = acc[i][2 * s], hi = acc[i][2 * s + 1];
+            if (EPI == EPI_PATCH) {
+                lo = lo + *reinterpret_cast<const f32x4 *>(posrow + col);
+                hi = hi + *reinterpret_cast<const f32x4 *>(posrow + col_hi);
+            }
             if (EPI == EPI_GELU) {
-                const f32x2 g0 = gelu_exact2(f32x2{lo[0], lo[1]}), g1 = gelu_exact2(f32x2{lo[2], lo[3]});
-                const f32x2 g2 = gelu_exact2(f32x2{hi[0], hi[1]}), g3 = gelu_exact2(f32x2{hi[2], hi[3]});
+                /* a result that is rounded to ONE bf16 part takes the GELU whose error is matched to that format */
+                auto gelu2 = [](f32x2 v) { return (NPL == 1 && OUTK == OUT_PLANES) ? gelu_lowp2<0>(v) : gelu_exact2(v); };
+                const f32x2 g0 = gelu2(f32x2{lo[0], lo[1]}), g1 = gelu2(f32x2{lo[2], lo[3]});
+                const f32x2 g2 = gelu2(f32x2{hi[0], hi[1]}), g3 = gelu2(f32x2{hi[2], hi[3]});
                 lo = f32x4{g0[0], g0[1], g1[0], g1[1]};
                 hi = f32x4{g2[0], g2[1], g3[0], g3[1]};
             }
-            if (EPI == EPI_RESID) {
-                const float *rp = p.R + (size_t)row * p.N + col;
-                lo = *reinterpret_cast<const f32x4 *>(rp) + lo;
-                hi = *reinterpret_cast<const f32x4 *>(rp + 4) + hi;
+            if (EPI == EPI_RESID && !R_IN_ACC) {
+                const float *rp = p.R + (size_t)row * p.N;
+                lo = *reinterpret_cast<const f32x4 *>(rp + col) + lo;
+                hi = *reinterpret_cast<const f32x4 *>(rp + col_hi) + hi;
             }
             if (LAB & 64) {   /* keep the values alive, store nothing */
                 asm volatile("" ::"v"(lo), "v"(hi));
@@ -271,9 +310,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
                 for (int pl = 0; pl < NPL; ++pl)
                     *reinterpret_cast<f32x4 *>(dst + pl * a_plane) = __builtin_bit_cast(f32x4, part[pl]);
             } else {
-                float *cp = static_cast<float *>(p.C) + (size_t)row * p.N + col;
-                *reinterpret_cast<f32x4 *>(cp) = lo;
-                *reinterpret_cast<f32x4 *>(cp + 4) = hi;
+                float *cp = static_cast<float *>(p.C) + orow * p.N;
+                *reinterpret_cast<f32x4 *>(cp + col) = lo;
+                *reinterpret_cast<f32x4 *>(cp + col_hi) = hi;
             }
         }
     }
@@ -306,6 +345,11 @@ int launch_p3(hipStream_t st, const P3Params &p, int small_only)
     const int num_cus = vh_device_cus(vh_current_device());
     const int ntiles = p.N / 256, mtiles = (rows + 255) / 256;
     const long tiles = (long)mtiles * ntiles;
+    /* One-part operands with the residual epilogue (the reduced modes' output projection and fc2): 128x256 tiles, 4
+     * waves of 32x256, two workgroups per CU -- one workgroup's stores of fp32 rows run under the other's K loop
+     * (measured, ViT-B/16 batch 512: out-proj 0.223 -> 0.213 ms, fc2 0.503 -> 0.491 against the rule below). */
+    if (EPI == EPI_RESID && NPL == 1 && p.N % 256 == 0 && tiles >= num_cus)
+        return launch_p3_tile<4, 256, EPI, OUTK, NPL>(st, p);
     if (p.N % 256 != 0 || small_only || 2 * tiles < 5 * (long)num_cus)
         return launch_p3_tile<4, 128, EPI, OUTK, NPL>(st, p);
     const long full = tiles / num_cus, rem = tiles % num_cus;
@@ -461,4 +505,121 @@ extern "C" int vh_launch_linear_p3(vh_stream_t s, void *output, int output_plane
 {
     return vh_launch_linear_planes(s, output, output_planes, weight_planes, input_planes, 3, bias, rowA, colA, colB,
                                    doGelu, residual);
+}
+
+/* ---- patch embedding on one-part planes (the reduced modes' conv_proj; replaces conv2d.cl:1-80 for them) ----
+ * The fp32 path gathers patch rows on load and splits both operands in the K loop (gemm_mfma.hip, A_PATCH).  Where the
+ * projections take bf16 operands anyway, an im2row producer writes the patches as one-part planes -- pixels rounded
+ * to bf16 once -- and the patch embedding is the planes GEMM with a token-row epilogue: K padded with zeros to the
+ * one-part K step (ViT-H/14: 3*14*14 = 588 -> 640), conv weights padded and rounded alike at context creation. */
+namespace {
+
+/* Thread i writes bytes [16 i, 16 i + 16) of planes[Kp/32][1][n_rows][32]: (K step kt, row m, chunk c) with c fastest
+ * -- stores are contiguous; for patch % 8 == 0 a lane's eight k are 32 contiguous bytes of one image row and the
+ * two chunks of a (row, kh) pair up to 64, consecutive patches of an image row to runs of a KiB. */
+__global__ void im2row_planes_kernel(const float *__restrict__ images, char *__restrict__ planes, int n_rows, int chans,
+                                     int img, int patch, int grid, int K, int Kp)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_rows * (Kp >> 3))
+        return;
+    const int c = (int)(i & 3);
+    const size_t rm = i >> 2;
+    const int kt = (int)(rm / n_rows), m = (int)(rm - (size_t)kt * n_rows);
+    const int k0 = 32 * kt + 8 * c;
+    const int np = grid * grid, b = m / np, pp = m - b * np, oh = pp / grid, ow = pp - oh * grid;
+    const float *base = images + ((size_t)b * chans * img + (size_t)oh * patch) * img + (size_t)ow * patch;
+    const int pp2 = patch * patch;
+    bf16x8 out;
+    if ((patch & 7) == 0 && (img & 3) == 0 && k0 + 8 <= K) {
+        const int ic = k0 / pp2, rem = k0 - ic * pp2, kh = rem / patch, kw = rem - kh * patch;
+        const float *src = base + ((size_t)ic * img + kh) * img + kw;
+        const f32x4 u = *reinterpret_cast<const f32x4 *>(src), v = *reinterpret_cast<const f32x4 *>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            out[e] = (__bf16)(e < 4 ? u[e] : v[e - 4]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            float v = 0.0f;
+            if (k < K) {
+                const int ic = k / pp2, rem = k - ic * pp2, kh = rem / patch, kw = rem - kh * patch;
+                v = base[((size_t)ic * img + kh) * img + kw];
+            }
+            out[e] = (__bf16)v;
+        }
+    }
+    *reinterpret_cast<f32x4 *>(planes + 16 * i) = __builtin_bit_cast(f32x4, out);
+}
+
+/* fp32 [rows][K] -> one-part planes [Kp/32][1][rows][32], zero beyond K (the conv weights, once) */
+__global__ void pad_rows_planes_kernel(const float *__restrict__ in, char *__restrict__ planes, int rows, int K, int Kp)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * (Kp >> 3))
+        return;
+    const int c = (int)(i & 3);
+    const size_t rm = i >> 2;
+    const int kt = (int)(rm / rows), r = (int)(rm - (size_t)kt * rows);
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 32 * kt + 8 * c + e;
+        out[e] = (__bf16)(k < K ? in[(size_t)r * K + k] : 0.0f);
+    }
+    *reinterpret_cast<f32x4 *>(planes + 16 * i) = __builtin_bit_cast(f32x4, out);
+}
+
+} // namespace
+
+extern "C" int vh_patch_planes_k(int in_chans, int patch_size)
+{
+    const int K = in_chans * patch_size * patch_size, step = 64 * P1_KG;
+    return (K + step - 1) / step * step;
+}
+
+extern "C" int vh_launch_conv_weight_planes(vh_stream_t s, const float *conv_w, void *planes, int embed_dim, int in_chans,
+                                            int patch_size)
+{
+    if (!conv_w || !planes || embed_dim <= 0 || in_chans <= 0 || patch_size <= 0 || ((uintptr_t)planes & 15))
+        return vh_fail(1, "vh_launch_conv_weight_planes: bad argument");
+    const int K = in_chans * patch_size * patch_size, Kp = vh_patch_planes_k(in_chans, patch_size);
+    const size_t threads = (size_t)embed_dim * (Kp / 8);
+    hipLaunchKernelGGL(pad_rows_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, conv_w,
+                       static_cast<char *>(planes), embed_dim, K, Kp);
+    VH_LAUNCH_CHECK("pad_rows_planes_kernel");
+    return 0;
+}
+
+extern "C" int vh_launch_patch_embed_planes(vh_stream_t s, const float *images, const void *conv_w_planes, const float *conv_b,
+                                            const float *cls_token, const float *pos_embed, float *tokens, int n_images,
+                                            int in_chans, int img_size, int patch_size, int embed_dim, void *workspace,
+                                            size_t workspace_bytes)
+{
+    if (!images || !conv_w_planes || !conv_b || !cls_token || !pos_embed || !tokens || !workspace)
+        return vh_fail(1, "vh_launch_patch_embed_planes: null pointer argument");
+    if (n_images <= 0 || in_chans <= 0 || img_size <= 0 || patch_size <= 0 || embed_dim <= 0 || img_size % patch_size != 0 ||
+        embed_dim % 128 != 0)
+        return vh_fail(1, "vh_launch_patch_embed_planes: bad geometry (embed_dim %% 128 == 0)");
+    const int grid = img_size / patch_size, K = in_chans * patch_size * patch_size, Kp = vh_patch_planes_k(in_chans, patch_size);
+    const long M = (long)n_images * grid * grid;
+    if (M * 64 > 0xffffffffl || workspace_bytes < (size_t)M * Kp * 2 ||
+        (((uintptr_t)workspace | (uintptr_t)conv_w_planes | (uintptr_t)images | (uintptr_t)conv_b | (uintptr_t)pos_embed | (uintptr_t)tokens) & 15))
+        return vh_fail(1, "vh_launch_patch_embed_planes: needs %zu bytes of 16-byte aligned workspace, aligned pointers", (size_t)M * Kp * 2);
+    hipStream_t st = (hipStream_t)s;
+    if (int rc = vh_cls_rows(st, cls_token, pos_embed, tokens, n_images, grid * grid + 1, embed_dim))
+        return rc;
+    const size_t threads = (size_t)M * (Kp / 8);
+    hipLaunchKernelGGL(im2row_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, images,
+                       static_cast<char *>(workspace), (int)M, in_chans, img_size, patch_size, grid, K, Kp);
+    VH_LAUNCH_CHECK("im2row_planes_kernel");
+    P3Params p = {};
+    p.A = static_cast<const char *>(workspace);
+    p.W = static_cast<const char *>(conv_w_planes);
+    p.bias = conv_b; p.C = tokens; p.pos = pos_embed;
+    p.row_begin = 0; p.row_end = (int)M; p.a_rows = (int)M;
+    p.N = embed_dim; p.K = Kp;
+    p.np = grid * grid; p.tokens = grid * grid + 1;
+    return launch_p3<EPI_PATCH, OUT_F32, 1>(st, p, Kp < 2048);   /* the shape of the output projection: small tiles (measured there) */
 }

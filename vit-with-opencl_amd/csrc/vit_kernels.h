@@ -47,6 +47,10 @@ int vh_hip_status(hipError_t e, const char *what);
 int vh_attention_tiled(void *stream, const float *qkv, void *output, int out_bf16, int lowp, int n_images, int tokens,
                        int embed_dim, int num_heads);
 
+/* gemm_mfma.hip: token 0 of every image = class token + pos_embed[0] (ViT_seq.c:90-93,114-117) */
+int vh_cls_rows(hipStream_t st, const float *cls_token, const float *pos_embed, float *tokens, int n_images,
+                int tokens_per_image, int embed_dim);
+
 /* Launch state that is per DEVICE (a process may hold contexts on several GPUs, one host thread each):
  * hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are cached per device id. */
 /* The caches are atomics: several host threads (one per device, or several contexts on one device) may fill a slot at

@@ -34,7 +34,8 @@ EXPORTS = [
     "ViT_opencl", "vit_hip_last_call_seconds", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
     "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_profile_select", "vit_hip_create_ex", "vit_hip_precision",
-    "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_launch_split3_planes", "vh_launch_linear_w3",
+    "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_patch_planes_k", "vh_launch_conv_weight_planes",
+    "vh_launch_patch_embed_planes", "vh_launch_split3_planes", "vh_launch_linear_w3",
     "vh_launch_split2h_planes", "vh_launch_linear_h2", "vh_launch_attention_h2", "vh_launch_attention_f16",
     "vh_launch_absmax",
     "vh_launch_split3_rows", "vh_launch_merge3_rows", "vh_launch_layer_norm_p3", "vh_launch_attention_p3",
@@ -146,6 +147,9 @@ def lib() -> C.CDLL:
     L.vh_launch_patch_embed.argtypes = [voidp] + [voidp] * 6 + [i] * 5
     L.vh_launch_patch_embed_ws.argtypes = [voidp] + [voidp] * 6 + [i] * 5 + [voidp, sz]
     L.vh_patch_embed_workspace.argtypes = [i] * 5
+    L.vh_patch_planes_k.argtypes = [i, i]
+    L.vh_launch_conv_weight_planes.argtypes = [voidp, voidp, voidp, i, i, i]
+    L.vh_launch_patch_embed_planes.argtypes = [voidp] + [voidp] * 6 + [i] * 5 + [voidp, sz]
     L.vh_patch_embed_workspace.restype = sz
     L.vh_launch_layer_norm.argtypes = [voidp] + [voidp] * 4 + [i, i, C.c_long, C.c_long, C.c_double]
     L.vh_launch_linear.argtypes = [voidp] + [voidp] * 4 + [i, i, i, i, voidp]
