@@ -154,6 +154,88 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def in_library_multi_child(n_dev: int, first_dev: int, B: int, steps: int) -> None:
+    """Child-process leg: the library's own multi-GPU entry (vit_hip_create_multi + vit_hip_forward_device_multi: one
+    replica per device inside ONE process, shards resident in HBM, the classifier gather over RCCL in C) on devices
+    first_dev .. first_dev + n_dev - 1.  Prints one JSON object.  No torch in this process: the library binds the system
+    HIP runtime and opens the system librccl itself."""
+    import ctypes as C
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    L = pkg.lib()
+    cfg = pkg.preset("vit_b_16")
+    NC, per = cfg.num_classes, cfg.in_chans * cfg.img_size * cfg.img_size
+    devices = list(range(first_dev, first_dev + n_dev))
+    weights = pkg.synth_weights(cfg, 0)
+    m = pkg.ViTHipMulti(cfg, weights, devices, max_batch_per_device=B)
+    d_imgs = []
+    for g, dev in enumerate(devices):          # shard g = global images g*B .. g*B+B-1, resident on device g
+        pkg.binding.check(L.vh_set_device(dev), "vh_set_device")
+        buf = pkg.DeviceBuffer(B * per)
+        for lo in range(0, B, 64):
+            k = min(64, B - lo)
+            chunk = pkg.synth_images(cfg, g * B + lo, k)
+            pkg.binding.check(L.vh_h2d(buf.ptr.value + lo * per * 4, chunk.ctypes.data, k * per * 4, None), "vh_h2d")
+            pkg.binding.check(L.vh_device_sync(), "sync")
+        d_imgs.append(buf)
+    pkg.binding.check(L.vh_set_device(devices[0]), "vh_set_device")
+    d_logits, d_probs = pkg.DeviceBuffer(n_dev * B * NC), pkg.DeviceBuffer(n_dev * B * NC)
+    counts = [B] * n_dev
+    ptrs = [b.ptr for b in d_imgs]
+    for _ in range(2):
+        m.forward_device(ptrs, counts, d_logits.ptr, d_probs.ptr)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.forward_device(ptrs, counts, d_logits.ptr, d_probs.ptr)     # synchronous on return
+    dt = (time.perf_counter() - t0) / steps
+    pkg.binding.check(L.vh_set_device(devices[0]), "vh_set_device")
+    got = d_logits.to_numpy((n_dev, B, NC))
+    probs = d_probs.to_numpy((n_dev * B, NC))
+    # every other shard's first and last 4 images recomputed by the root's replica on the same batch positions
+    edge = sorted(set(list(range(min(4, B))) + list(range(max(B - 4, 0), B))))
+    one = pkg.ViTHip(cfg, weights, device=devices[0], max_batch=B)
+    d_chk = pkg.DeviceBuffer(B * NC)
+    verified = 0
+    for g in range(1, n_dev):
+        for i in edge:
+            img = pkg.synth_images(cfg, g * B + i, 1)
+            pkg.binding.check(L.vh_h2d(d_imgs[0].ptr.value + i * per * 4, img.ctypes.data, per * 4, None), "vh_h2d")
+        pkg.binding.check(L.vh_device_sync(), "sync")
+        one.forward_device(d_imgs[0].ptr, B, d_chk.ptr, None, one.stream)
+        pkg.binding.check(L.vh_device_sync(), "sync")
+        if not np.array_equal(d_chk.to_numpy((B, NC))[edge], got[g][edge]):
+            raise SystemExit(f"in-library multi-GPU leg: rows gathered from device {devices[g]} differ from the root's recomputation")
+        verified += 1
+    one.close()
+    m.close()
+    print(json.dumps({"what": "vit_hip_create_multi + vit_hip_forward_device_multi: one process, one replica and one stream per "
+                              "device, image shards resident in HBM, logits gathered on the first device by grouped "
+                              "ncclSend/ncclRecv in C (librccl opened at run time), softmax of all rows on the root; "
+                              "synchronous per step", "devices": devices, "batch_per_device": B, "steps": steps,
+                      "value": round(n_dev * B / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3),
+                      "gathered_shards_verified_bitwise": verified, "logits_finite": bool(np.isfinite(got).all()),
+                      "prob_sum_last_image": float(probs[-1].sum())}), flush=True)
+
+
+def run_in_library_multi(n_dev: int, first_dev: int, B: int) -> dict:
+    """Run the leg above in a child process (bounded by a timeout; a failure there cannot take this run down)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                              "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                                              "TORCHELASTIC_RUN_ID", "VIT_DIST_FORCE", "VIT_DIST_BACKEND")}
+    env["VIT_HIP_NO_TORCH"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--in-library-multi-child", str(n_dev), "--first-device", str(first_dev),
+           "--batch", str(B), "--steps", "5"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after 240 s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"exit status {r.returncode}", "stderr_tail": r.stderr[-600:]}
+    return json.loads(lines[-1])
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,7 +250,12 @@ def main() -> None:
     ap.add_argument("--model", choices=["vit_b_16", "vit_l_16", "vit_h_14"], default="vit_b_16",
                     help="vit_b_16 is BASELINE.json's metric; the others are the parity-test shapes, timed for DESIGN.md")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-in-library-multi", action="store_true", help="skip the in-library multi-GPU leg (child process)")
+    ap.add_argument("--in-library-multi-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--first-device", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.in_library_multi_child:
+        return in_library_multi_child(args.in_library_multi_child, args.first_device, args.batch, args.steps)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks as children of this process, which has
@@ -604,12 +691,18 @@ def main() -> None:
                     parity_failed = f"parity {out['parity']['max_abs_dlogit_vs_ViT_seq']:.3e} exceeds {tol} (or arg-max differs)"
         out["checks"] = {"logits_finite": bool(np.isfinite(logits0).all()),
                          "prob_sum_image0": float(probs0.sum())}
+        if args.dtype == "f32" and args.model == "vit_b_16" and not args.no_in_library_multi:
+            # the library's own multi-GPU entry (RCCL gather in C) on the same devices, in a child process, while the
+            # other ranks wait on the host (Comm.rank0_says_done): beside `value`, never instead of it
+            one_card = "VIT_BENCH_DEVICE" in os.environ
+            out["in_library_multi_gpu"] = run_in_library_multi(1 if one_card else world, device if one_card else 0, B)
         print(json.dumps(out), flush=True)
         if parity_failed or not out["checks"]["logits_finite"]:
             failed = parity_failed or "non-finite logits"
 
     model.close()
     if comm is not None:
+        comm.rank0_says_done()      # ranks > 0 wait here, on the host, while rank 0 ran its CPU baseline and checks
         comm.close()
     if failed:
         raise SystemExit("bench.py: " + failed)

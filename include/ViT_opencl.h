@@ -130,6 +130,14 @@ int vit_hip_forward_multi(vit_hip_multi *m, const ImageData *images, int n, floa
 void vit_hip_destroy_multi(vit_hip_multi *m);
 int vit_hip_multi_devices(const vit_hip_multi *m);
 vit_hip_ctx *vit_hip_multi_ctx(const vit_hip_multi *m, int i);
+int vit_hip_device(const vit_hip_ctx *ctx);   /* the device a context lives on */
+/* Device-resident form with the classifier gather over RCCL (the one exchange of the path; grouped ncclSend / ncclRecv
+ * between the devices' compute streams, device 0 of `m` is the root): d_images[g] = shard g's images, [counts[g]][C][H][W]
+ * fp32 resident on device g of `m` (counts[g] <= max_batch_per_device); d_logits_root and d_probs_root (may be NULL) =
+ * [sum counts][classes] fp32 on device 0, shard after shard.  Synchronous on return.  librccl is opened at run time on
+ * first use (an RCCL already in the process, e.g. PyTorch's, is taken); devices must be distinct. */
+int vit_hip_forward_device_multi(vit_hip_multi *m, const float *const *d_images, const int *counts, float *d_logits_root,
+                                 float *d_probs_root);
 /* The sharding primitives on their own (host logic, no device needed): shard `shard` of [0, total) cut
  * into n_shards contiguous pieces of ceil(total / n_shards); and a runner that calls
  * fn(arg, shard, lo, hi) for every non-empty shard, each on its own host thread, and returns 0 or the

@@ -48,6 +48,7 @@ typedef void *vh_event_t;  /* hipEvent_t  */
 int vh_device_count(void);                 /* number of visible HIP devices (0 if none / no driver) */
 int vh_init(int device);                   /* select `device`; fails unless it is a gfx950 part */
 const char *vh_last_error(void);           /* text of the last failure on this thread ("" if none) */
+int vh_set_error(int code, const char *message);   /* record `message` as this thread's last error; returns code (1 if 0) */
 const char *vh_device_name(void);          /* e.g. "AMD Instinct MI355X (gfx950, 256 CUs)" */
 int vh_set_device(int device);             /* make `device` current for the calling thread (after vh_init) */
 

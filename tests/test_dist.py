@@ -57,3 +57,5 @@ def test_bench_two_ranks_launch_themselves_verify_the_gather_and_report_the_cpu_
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] in ("reference", "port")
     assert out["parity"]["max_abs_dlogit_vs_ViT_seq"] <= 1e-4 and out["parity"]["argmax_equal"]
     assert out["checks"]["logits_finite"]
+    lib_leg = out["in_library_multi_gpu"]          # the C-side RCCL entry, degenerate group of one on this box
+    assert "error" not in lib_leg and lib_leg["devices"] == [0] and lib_leg["value"] > 0 and lib_leg["logits_finite"]

@@ -425,6 +425,34 @@ def test_multi_device_entry_is_bit_identical_to_one_context(pkg, device, weights
         pkg.ViTHipMulti(cfg, weights, [0, 99], max_batch_per_device=2)      # no such device: loud failure
 
 
+def test_device_resident_multi_entry_with_the_rccl_gather_in_c(pkg, device, weights):
+    """vit_hip_forward_device_multi ("RCCL over xGMI only for the final classifier gather", below Python):
+    per-device image pointers in, logits gathered on device 0 by grouped ncclSend / ncclRecv on the compute streams.  This
+    box has one GPU: the degenerate group devices = [0] (ncclCommInitAll of one, the root's shard written in place) must
+    equal the single-context path bit for bit, twice in a row (the communicator is kept); two replicas on ONE device are
+    refused loudly (RCCL needs distinct devices), as is a shard larger than max_batch.  N > 1: bench.py's
+    in_library_multi_gpu leg."""
+    cfg = pkg.preset("vit_b_16")
+    n = 5
+    imgs = pkg.synth_images(cfg, 40, n)
+    one = pkg.ViTHip(cfg, weights, device=0, max_batch=n)
+    base, base_p = one.forward(imgs)
+    one.close()
+    d_img = pkg.DeviceBuffer.from_numpy(imgs)
+    d_l, d_p = pkg.DeviceBuffer(n * 1000), pkg.DeviceBuffer(n * 1000)
+    m = pkg.ViTHipMulti(cfg, weights, [0], max_batch_per_device=n)
+    for _ in range(2):
+        m.forward_device([d_img.ptr], [n], d_l.ptr, d_p.ptr)
+        assert np.array_equal(d_l.to_numpy((n, 1000)), base) and np.array_equal(d_p.to_numpy((n, 1000)), base_p)
+    with pytest.raises(pkg.VitHipError, match="max_batch"):
+        m.forward_device([d_img.ptr], [n + 1], d_l.ptr, None)
+    m.close()
+    m2 = pkg.ViTHipMulti(cfg, weights, [0, 0], max_batch_per_device=3)
+    with pytest.raises(pkg.VitHipError, match="distinct"):
+        m2.forward_device([d_img.ptr, d_img.ptr], [3, 2], d_l.ptr, None)
+    m2.close()
+
+
 def test_torch_interop_shares_one_hip_runtime(pkg, device, weights, golden_full):
     """bench.py hands torch-allocated HBM to the library (torch.distributed needs
     the logits in a torch tensor for the RCCL gather)."""

@@ -139,6 +139,8 @@ static double wall_seconds(void)
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 const vit_config *vit_hip_config(const vit_hip_ctx *ctx) { return &ctx->cfg; }
+int vit_hip_device(const vit_hip_ctx *ctx) { return ctx->device; }
+float *vit_hip_logits_buffer(vit_hip_ctx *ctx) { return ctx->d_logits; }   /* [max_batch][classes], vit_gather_rccl.c */
 vh_stream_t vit_hip_stream(const vit_hip_ctx *ctx) { return ctx->stream; }
 int vit_hip_max_batch(const vit_hip_ctx *ctx) { return ctx->max_batch; }
 const float *vit_hip_weight(const vit_hip_ctx *ctx, int idx)
@@ -869,7 +871,11 @@ struct vit_hip_multi
     const ImageData *images;
     float *logits;
     float **probs;
+    void *gather;   /* RCCL communicators of vit_hip_forward_device_multi (vit_gather_rccl.c), made on first use */
 };
+
+void vit_gather_release(void *state);
+void **vit_hip_multi_gather_slot(vit_hip_multi *m) { return &m->gather; }
 
 static int multi_create_one(void *arg, int shard, int lo, int hi)
 {
@@ -921,6 +927,7 @@ void vit_hip_destroy_multi(vit_hip_multi *m)
 {
     if (!m)
         return;
+    vit_gather_release(m->gather);
     for (int d = 0; d < m->n_devices; ++d)
         vit_hip_destroy(m->ctx[d]);
     free((void *)m->devices);

@@ -39,6 +39,7 @@ int vh_hip_status(hipError_t e, const char *what)
 extern "C" {
 
 const char *vh_last_error(void) { return g_err; }
+int vh_set_error(int code, const char *message) { return vh_fail(code, "%s", message ? message : ""); }
 
 int vh_device_count(void)
 {

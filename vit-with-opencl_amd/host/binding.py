@@ -46,7 +46,7 @@ EXPORTS = [
     "vh_launch_attention_planes_f16_hd80",
     "vh_launch_gather_rows", "vit_hip_set_last_layer_cls_only",
     "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
-    "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run",
+    "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run", "vit_hip_forward_device_multi", "vit_hip_device", "vh_set_error",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
     "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
     "vit_write_result_file", "vit_compare_rows",
@@ -205,6 +205,9 @@ def lib() -> C.CDLL:
     L.vit_hip_multi_devices.argtypes = [voidp]
     L.vit_hip_multi_ctx.argtypes = [voidp, i]
     L.vit_hip_multi_ctx.restype = voidp
+    L.vit_hip_device.argtypes = [voidp]
+    L.vit_hip_forward_device_multi.argtypes = [voidp, C.POINTER(voidp), C.POINTER(i), voidp, voidp]
+    L.vh_set_error.argtypes = [i, C.c_char_p]
     L.vit_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     L.vit_shard_range.restype = None
     L.vit_shard_run.argtypes = [i, i, SHARD_FN, voidp]
@@ -426,6 +429,13 @@ class ViTHipMulti:
         rows = (f32p * n)(*[fptr(probs[i]) for i in range(n)])
         check(self.L.vit_hip_forward_multi(self.handle, image_array(images), n, fptr(logits), rows), "vit_hip_forward_multi")
         return logits, probs
+
+    def forward_device(self, d_images: list, counts: list[int], d_logits_root, d_probs_root=None):
+        """Device-resident shards (d_images[g] on device g), logits gathered onto device 0 over RCCL (C side)."""
+        n = len(counts)
+        ptrs = (voidp * n)(*[p if isinstance(p, voidp) else voidp(p) for p in d_images])
+        check(self.L.vit_hip_forward_device_multi(self.handle, ptrs, (C.c_int * n)(*counts), d_logits_root, d_probs_root),
+              "vit_hip_forward_device_multi")
 
     def close(self):
         if self.handle:

@@ -63,6 +63,19 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def rank0_says_done(self, timeout_s: int = 1200) -> None:
+        """Host-side hand-over through the rendezvous store: rank 0 calls it when its rank-0-only work (CPU baseline,
+        checks) is finished, every other rank blocks in it until then -- on the CPU, with no collective kernel
+        spinning on its GPU meanwhile (an RCCL barrier would)."""
+        if not self.active or self.world == 1:
+            return
+        from datetime import timedelta
+        store = dist.distributed_c10d._get_default_store()
+        if self.rank == 0:
+            store.set("vit_rank0_done", "1")
+        else:
+            store.wait(["vit_rank0_done"], timedelta(seconds=timeout_s))
+
     def close(self) -> None:
         if self.active:
             dist.barrier()
