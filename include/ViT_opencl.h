@@ -87,6 +87,15 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
                       int n_tensors, int device, int max_batch, int precision);
 int vit_hip_precision(const vit_hip_ctx *ctx);
 
+/* Repacked weights on disk (the offline half of the weight-format tooling): export writes what the context holds in HBM
+ * after its repack -- every tensor in fp32 (reference order) plus the precision's GEMM-operand copy of the four big
+ * matrices of every layer (three-part bf16 planes / one-part planes / fp16 pairs / MX values + scales) -- behind a
+ * header that pins the model shape and precision; create_from_planes builds an identical context from that ONE file
+ * (three reads into three allocations; the reference's loader opens 152 files, Network.c:134-218).  Logits of the two
+ * contexts are bit-identical. */
+int vit_hip_export_planes(vit_hip_ctx *ctx, const char *path);
+int vit_hip_create_from_planes(vit_hip_ctx **out, const char *path, int device, int max_batch);
+
 /* FP8_GEMM (BASELINE config 5: "fp8 weights (CDNA4 fp8 MFMA)"): the same four matrices and their inputs as block-scaled
  * fp8 -- OCP "MX": e4m3 elements, one power-of-two scale per 32 consecutive K elements, computed where the tensor
  * is produced (weights at context creation; LayerNorm, the fc1 epilogue and the attention output at run time), so

@@ -747,3 +747,32 @@ def test_resident_fp16_planes_attention_for_head_dim_80(pkg, device, oracle, n_i
     L = pkg.lib()
     assert L.vh_launch_attention_planes_f16_hd80(None, d_qh.ptr, d_c.ptr, n_images, 273, E, H) != 0
     assert L.vh_launch_attention_planes_f16_hd80(None, d_qh.ptr, d_c.ptr, n_images, tokens, 1024, H) != 0
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "fp8", "f32_fp16x2"])
+def test_repacked_weights_file_round_trip_is_bit_identical(pkg, device, weights, tmp_path, precision):
+    """vit_hip_export_planes / vit_hip_create_from_planes (the offline repack; the reference's loader reads
+    152 fp32 files per run, Network.c:134-218): a context built from ONE file of already repacked operands -- three-part
+    planes, one-part planes, MX values + scales, fp16 pairs with their per-tensor scales -- gives the same logits and
+    probabilities, bit for bit, as the context that wrote it; a truncated or foreign file is refused."""
+    cfg = pkg.preset("vit_b_16")
+    imgs = pkg.synth_images(cfg, 7, 3)
+    a = pkg.ViTHip(cfg, weights, device=0, max_batch=3, precision=precision)
+    la, pa = a.forward(imgs)
+    path = tmp_path / f"b16_{precision}.planes"
+    a.export_planes(path)
+    a.close()
+    per_weight = {"f32": 6, "bf16": 2, "fp8": 1 + 1 / 32, "f32_fp16x2": 4}[precision]
+    big = sum(weights[4 + 12 * l + k].size for l in range(12) for k in (2, 4, 8, 10))
+    assert path.stat().st_size >= 4 * sum(w.size for w in weights) + per_weight * big      # fp32 slab + operand slab (+ padding, header)
+    b = pkg.ViTHip.from_planes(path, device=0, max_batch=3)
+    assert b.precision == precision and b.cfg.embed_dim == 768 and b.cfg.depth == 12
+    lb, pb = b.forward(imgs)
+    b.close()
+    assert np.array_equal(la, lb) and np.array_equal(pa, pb)
+    raw = path.read_bytes()
+    (tmp_path / "short.planes").write_bytes(raw[:len(raw) // 2])
+    (tmp_path / "foreign.planes").write_bytes(b"NOTAPLAN" + raw[8:4096])
+    for bad in ("short.planes", "foreign.planes", "missing.planes"):
+        with pytest.raises(pkg.VitHipError):
+            pkg.ViTHip.from_planes(tmp_path / bad, device=0, max_batch=3)

@@ -61,6 +61,7 @@ struct vit_hip_ctx
     void **w8, **w8s;   /* per tensor index: values, scales */
     /* BF16_GEMM / FP8_GEMM: conv_proj as one-part bf16 planes [Kp/32][1][E][32] (vh_launch_patch_embed_planes) */
     void *wconv16;
+    size_t w_slab_bytes, planes_bytes, wconv16_bytes;   /* sizes of w_slab, of the mode's repacked slab, of wconv16 */
 
     /* activation arena (rows = max_batch * tokens) */
     float *x;           /* residual stream      [rows][E]   */
@@ -192,6 +193,137 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
     free(ctx);
 }
 
+static const int BIG[4] = {2, 4, 8, 10};   /* in_proj, out_proj, fc1, fc2 weights within a layer's 12 tensors */
+
+/* bytes per weight of the mode's repacked copy of the four big matrices (0: none) */
+static size_t repack_bytes_per_weight(const vit_hip_ctx *ctx)
+{
+    const vit_config *cfg = &ctx->cfg;
+    switch (ctx->precision) {
+    case VIT_PRECISION_BF16_GEMM: return 2;                                                   /* one-part planes */
+    case VIT_PRECISION_F32: return (cfg->embed_dim % 128 == 0 && cfg->mlp_hidden % 128 == 0) ? 6 : 0;   /* three-part planes */
+    case VIT_PRECISION_F32_FP16X2: return 4;                                                  /* two fp16 parts */
+    default: return 0;                                                                        /* FP8: values + scales, below */
+    }
+}
+
+/* Allocate the weight slabs and fix every tensor's place in them.  Depends on (cfg, precision) only, so a planes file
+ * written by one context (vit_hip_export_planes) drops into another's slabs byte for byte. */
+static int layout_weights(vit_hip_ctx *ctx)
+{
+    int rc = 0;
+    const vit_config *cfg = &ctx->cfg;
+    const int n_tensors = ctx->n_tensors;
+    size_t total = 0;
+    for (int i = 0; i < n_tensors; ++i)
+        total += align_up(vit_config_tensor_size(cfg, i) * sizeof(float), 256);
+    ctx->w_slab_bytes = total;
+    TRY(vh_malloc((void **)&ctx->w_slab, total));
+    size_t off = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        ctx->w[i] = (float *)((char *)ctx->w_slab + off);
+        off += align_up(vit_config_tensor_size(cfg, i) * sizeof(float), 256);
+    }
+    const size_t per = repack_bytes_per_weight(ctx);
+    size_t planes = 0;
+    for (int l = 0; l < cfg->depth; ++l)
+        for (int k = 0; k < 4; ++k) {
+            const size_t cnt = vit_config_tensor_size(cfg, 4 + 12 * l + BIG[k]);
+            planes += ctx->precision == VIT_PRECISION_FP8_GEMM ? align_up(cnt, 256) + align_up(cnt / 32, 256) : align_up(cnt * per, 256);
+        }
+    ctx->planes_bytes = planes;
+    if (planes) {
+        void *slab = NULL;
+        TRY(vh_malloc(&slab, planes));
+        if (ctx->precision == VIT_PRECISION_BF16_GEMM)
+            ctx->w16_slab = slab;
+        else if (ctx->precision == VIT_PRECISION_FP8_GEMM)
+            ctx->w8_slab = slab;
+        else
+            ctx->w3_slab = slab;
+        size_t o = 0;
+        for (int l = 0; l < cfg->depth; ++l)
+            for (int k = 0; k < 4; ++k) {
+                const int idx = 4 + 12 * l + BIG[k];
+                const size_t cnt = vit_config_tensor_size(cfg, idx);
+                if (ctx->precision == VIT_PRECISION_BF16_GEMM) {
+                    ctx->w16[idx] = (char *)slab + o;
+                    o += align_up(cnt * 2, 256);
+                } else if (ctx->precision == VIT_PRECISION_FP8_GEMM) {
+                    /* values (1 byte per weight) then the e8m0 scales (1 byte per 32 weights), both 256-byte aligned */
+                    ctx->w8[idx] = (char *)slab + o;
+                    ctx->w8s[idx] = (char *)slab + o + align_up(cnt, 256);
+                    o += align_up(cnt, 256) + align_up(cnt / 32, 256);
+                } else {
+                    ctx->w3[idx] = (char *)slab + o;
+                    o += align_up(cnt * per, 256);
+                }
+            }
+    }
+    if ((ctx->precision == VIT_PRECISION_BF16_GEMM || ctx->precision == VIT_PRECISION_FP8_GEMM) && cfg->embed_dim % 128 == 0) {
+        /* the reduced modes' patch embedding: conv weights rounded to bf16 planes, K padded to the one-part K step */
+        ctx->wconv16_bytes = (size_t)vh_patch_planes_k(cfg->in_chans, cfg->patch_size) * (size_t)cfg->embed_dim * 2;
+        TRY(vh_malloc(&ctx->wconv16, ctx->wconv16_bytes));
+    }
+    return 0;
+fail:
+    return rc;
+}
+
+/* Upload the caller's tensors and repack the four big matrices of every layer into the mode's GEMM operand format. */
+static int fill_weights(vit_hip_ctx *ctx, const Network *networks)
+{
+    int rc = 0;
+    const vit_config *cfg = &ctx->cfg;
+    for (int i = 0; i < ctx->n_tensors; ++i)
+        TRY(vh_h2d(ctx->w[i], networks[i].data, networks[i].size * sizeof(float), ctx->stream));
+    float *d_amax = NULL;
+    if (ctx->precision == VIT_PRECISION_F32_FP16X2)
+        TRY(vh_malloc((void **)&d_amax, sizeof(float)));
+    for (int l = 0; l < cfg->depth && rc == 0; ++l)
+        for (int k = 0; k < 4 && rc == 0; ++k) {
+            const int idx = 4 + 12 * l + BIG[k];
+            const int out_f = (int)networks[idx + 1].size, in_f = (int)(networks[idx].size / networks[idx + 1].size);
+            if (ctx->precision == VIT_PRECISION_BF16_GEMM) {
+                /* one-part planes [K/32][1][N][32] (gemm_p3.hip); everything else (norms, biases, embeddings, classifier) stays fp32 */
+                rc = vh_launch_split_rows(ctx->stream, ctx->w[idx], ctx->w16[idx], out_f, in_f, 1);
+            } else if (ctx->precision == VIT_PRECISION_F32 && ctx->w3_slab) {
+                /* the constant GEMM operand split once (exact 3-way bf16 split, 6 bytes per weight) */
+                rc = vh_launch_split3_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], out_f, in_f);
+            } else if (ctx->precision == VIT_PRECISION_FP8_GEMM) {
+                rc = vh_launch_quantize_mx_rows(ctx->stream, ctx->w[idx], ctx->w8[idx], ctx->w8s[idx], out_f, in_f);
+            } else if (ctx->precision == VIT_PRECISION_F32_FP16X2) {
+                /* two fp16 parts of w * 2^k per weight (4 bytes), k per tensor such that max|w| * 2^k lands in
+                 * [8192, 16384): the low part stays clear of fp16's subnormals, nothing overflows */
+                float amax = 0.0f;
+                if ((rc = vh_memset(d_amax, 0, sizeof(float), ctx->stream)) != 0 ||
+                    (rc = vh_launch_absmax(ctx->stream, ctx->w[idx], networks[idx].size, d_amax)) != 0 ||
+                    (rc = vh_d2h(&amax, d_amax, sizeof(float), ctx->stream)) != 0 ||
+                    (rc = vh_stream_sync(ctx->stream)) != 0)
+                    break;
+                int e = 0;
+                float scale = 1.0f;
+                if (amax > 0.0f && amax < 3.0e38f) {
+                    (void)frexpf(amax, &e);                 /* amax = m * 2^e, m in [0.5, 1) */
+                    scale = ldexpf(1.0f, 14 - e);           /* amax * scale in [8192, 16384) */
+                }
+                ctx->w3_scale[idx] = scale;
+                rc = vh_launch_split2h_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], out_f, in_f, scale);
+            }
+        }
+    if (d_amax)
+        vh_free(d_amax);
+    if (rc)
+        return rc;
+    if (ctx->wconv16)
+        TRY(vh_launch_conv_weight_planes(ctx->stream, ctx->w[1], ctx->wconv16, cfg->embed_dim, cfg->in_chans, cfg->patch_size));
+    return 0;
+fail:
+    return rc;
+}
+
+static int alloc_arena(vit_hip_ctx *ctx);
+
 /* $VIT_HIP_PRECISION: F32 unless asked otherwise: "bf16" -> BF16_GEMM, "fp16x2" -> F32_FP16X2, "fp8" -> FP8_GEMM */
 static int env_precision(void)
 {
@@ -209,14 +341,13 @@ int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *netw
 
 int vit_hip_precision(const vit_hip_ctx *ctx) { return ctx->precision; }
 
-int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
-                      int n_tensors, int device, int max_batch, int precision)
+/* Argument checks shared by both ways of making a context, and the empty context itself. */
+static int ctx_new(vit_hip_ctx **out, const vit_config *cfg, int n_tensors, int device, int max_batch, int precision)
 {
-    int rc = 0;
     if (!out)
         return 1;
     *out = NULL;
-    if (!cfg || !networks || max_batch <= 0)
+    if (!cfg || max_batch <= 0)
         return 1;
     if (precision != VIT_PRECISION_F32 && precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM &&
         precision != VIT_PRECISION_F32_FP16X2)
@@ -227,19 +358,13 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
         return 2;
     if (precision == VIT_PRECISION_BF16_GEMM && (cfg->embed_dim % 128 != 0 || cfg->mlp_hidden % 128 != 0))
         return 2;
+    if (cfg->depth <= 0 || cfg->embed_dim <= 0 || cfg->num_heads <= 0 || cfg->patch_size <= 0 || cfg->img_size <= 0 ||
+        cfg->in_chans <= 0 || cfg->num_classes <= 0 || cfg->mlp_hidden <= 0)
+        return 2;
     if (n_tensors != vit_config_num_tensors(cfg))
         return 2;
     if (cfg->embed_dim % cfg->num_heads != 0 || cfg->img_size % cfg->patch_size != 0)
         return 2;
-    /* The reference never checks its tensors (a missing file is a NULL
-     * dereference, Network.c:144-148); here a wrong count is an error. */
-    for (int i = 0; i < n_tensors; ++i)
-        if (!networks[i].data || networks[i].size != vit_config_tensor_size(cfg, i)) {
-            fprintf(stderr, "vit_hip_create: tensor %d has %zu elements, expected %zu\n", i,
-                    networks[i].data ? networks[i].size : (size_t)0, vit_config_tensor_size(cfg, i));
-            return 3;
-        }
-
     vit_hip_ctx *ctx = (vit_hip_ctx *)calloc(1, sizeof(*ctx));
     if (!ctx)
         return 4;
@@ -265,131 +390,189 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
         free(ctx);
         return 4;
     }
+    *out = ctx;
+    return 0;
+}
 
+int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
+                      int n_tensors, int device, int max_batch, int precision)
+{
+    int rc = 0;
+    if (!out)
+        return 1;
+    *out = NULL;
+    if (!networks || !cfg)
+        return 1;
+    if (n_tensors != vit_config_num_tensors(cfg))
+        return 2;
+    /* The reference never checks its tensors (a missing file is a NULL
+     * dereference, Network.c:144-148); here a wrong count is an error. */
+    for (int i = 0; i < n_tensors; ++i)
+        if (!networks[i].data || networks[i].size != vit_config_tensor_size(cfg, i)) {
+            fprintf(stderr, "vit_hip_create: tensor %d has %zu elements, expected %zu\n", i,
+                    networks[i].data ? networks[i].size : (size_t)0, vit_config_tensor_size(cfg, i));
+            return 3;
+        }
+    vit_hip_ctx *ctx = NULL;
+    if ((rc = ctx_new(&ctx, cfg, n_tensors, device, max_batch, precision)) != 0)
+        return rc;
     TRY(vh_init(device));
     TRY(vh_stream_create(&ctx->stream));
+    TRY(layout_weights(ctx));
+    TRY(fill_weights(ctx, networks));
+    TRY(alloc_arena(ctx));
+    *out = ctx;
+    return 0;
+fail:
+    vit_hip_destroy(ctx);
+    return rc;
+}
 
-    /* one slab for all weights; 256-byte aligned tensors */
-    size_t total = 0;
-    for (int i = 0; i < n_tensors; ++i)
-        total += align_up(networks[i].size * sizeof(float), 256);
-    TRY(vh_malloc((void **)&ctx->w_slab, total));
-    size_t off = 0;
-    for (int i = 0; i < n_tensors; ++i) {
-        ctx->w[i] = (float *)((char *)ctx->w_slab + off);
-        TRY(vh_h2d(ctx->w[i], networks[i].data, networks[i].size * sizeof(float), ctx->stream));
-        off += align_up(networks[i].size * sizeof(float), 256);
-    }
+/* ---- repacked weights on disk (the offline half of the weight-format tooling) --------------------------
+ * vit_hip_export_planes writes what a context holds in HBM after its repack -- the fp32 slab (all tensors, the
+ * reference's order, 256-byte aligned) followed by the mode's operand slab for the four big matrices of every layer
+ * (three-part bf16 planes, one-part planes, two fp16 parts, or MX values + scales: csrc/gemm_p3.hip, gemm_mx.hip) and,
+ * in the reduced modes, the conv_proj planes -- behind a header that pins model shape and precision.  Both slabs'
+ * layouts follow from (config, precision) alone (layout_weights), so vit_hip_create_from_planes is three reads into
+ * three allocations: no fp32 -> format pass, no per-tensor files (the reference's loader opens 152 of them,
+ * Network.c:134-218). */
+struct planes_header
+{
+    char magic[8];                 /* "VITPLN01" */
+    unsigned header_bytes;
+    int precision, n_tensors;
+    int cfg_ints[8];               /* img, patch, chans, classes, embed, depth, heads, mlp_hidden */
+    double eps;
+    unsigned long long w_slab_bytes, planes_bytes, wconv16_bytes, scale_floats;   /* scale_floats = n_tensors (w3_scale) */
+};
 
-    if (precision == VIT_PRECISION_BF16_GEMM) {
-        /* bf16 copies of in_proj, out_proj, fc1, fc2 of every layer (the GEMM operands);
-         * everything else (norms, biases, embeddings, classifier) stays fp32 */
-        static const int big[4] = {2, 4, 8, 10};
-        size_t total16 = 0;
-        for (int l = 0; l < cfg->depth; ++l)
-            for (int k = 0; k < 4; ++k)
-                total16 += align_up(networks[4 + 12 * l + big[k]].size * 2, 256);
-        TRY(vh_malloc(&ctx->w16_slab, total16));
-        size_t off16 = 0;
-        for (int l = 0; l < cfg->depth; ++l)
-            for (int k = 0; k < 4; ++k) {
-                const int idx = 4 + 12 * l + big[k];
-                ctx->w16[idx] = (char *)ctx->w16_slab + off16;
-                /* one-part planes [K/32][1][N][32] (gemm_p3.hip) */
-                TRY(vh_launch_split_rows(ctx->stream, ctx->w[idx], ctx->w16[idx], (int)networks[idx + 1].size,
-                                         (int)(networks[idx].size / networks[idx + 1].size), 1));
-                off16 += align_up(networks[idx].size * 2, 256);
+static int copy_file_and_device(vit_hip_ctx *ctx, FILE *fp, void *dev, size_t bytes, int to_file)
+{
+    enum { CHUNK = 64 << 20 };
+    int rc = 0;
+    void *host = NULL;
+    if (bytes == 0)
+        return 0;
+    TRY(vh_host_alloc(&host, bytes < CHUNK ? bytes : (size_t)CHUNK));
+    for (size_t off = 0; off < bytes && rc == 0; off += CHUNK) {
+        const size_t n = bytes - off < CHUNK ? bytes - off : (size_t)CHUNK;
+        if (to_file) {
+            if ((rc = vh_d2h(host, (char *)dev + off, n, ctx->stream)) != 0 || (rc = vh_stream_sync(ctx->stream)) != 0)
+                break;
+            if (fwrite(host, 1, n, fp) != n)
+                rc = vh_set_error(120, "vit_hip_export_planes: short write");
+        } else {
+            if (fread(host, 1, n, fp) != n) {
+                rc = vh_set_error(121, "vit_hip_create_from_planes: file is shorter than its header says");
+                break;
             }
+            if ((rc = vh_h2d((char *)dev + off, host, n, ctx->stream)) != 0 || (rc = vh_stream_sync(ctx->stream)) != 0)
+                break;
+        }
     }
+fail:
+    if (host)
+        vh_host_free(host);
+    return rc;
+}
 
-    if (precision == VIT_PRECISION_F32 && cfg->embed_dim % 128 == 0 &&
-        cfg->mlp_hidden % 128 == 0) {
-        /* the constant GEMM operand split once (exact 3-way bf16 split, 6 bytes per weight) */
-        static const int big[4] = {2, 4, 8, 10};
-        size_t total3 = 0;
-        for (int l = 0; l < cfg->depth; ++l)
-            for (int k = 0; k < 4; ++k)
-                total3 += align_up(networks[4 + 12 * l + big[k]].size * 6, 256);
-        TRY(vh_malloc(&ctx->w3_slab, total3));
-        size_t off3 = 0;
-        for (int l = 0; l < cfg->depth; ++l)
-            for (int k = 0; k < 4; ++k) {
-                const int idx = 4 + 12 * l + big[k];
-                ctx->w3[idx] = (char *)ctx->w3_slab + off3;
-                TRY(vh_launch_split3_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], (int)networks[idx + 1].size,
-                                            (int)(networks[idx].size / networks[idx + 1].size)));
-                off3 += align_up(networks[idx].size * 6, 256);
-            }
+static void *planes_slab(const vit_hip_ctx *ctx)
+{
+    return ctx->precision == VIT_PRECISION_BF16_GEMM ? ctx->w16_slab : ctx->precision == VIT_PRECISION_FP8_GEMM ? ctx->w8_slab : ctx->w3_slab;
+}
+
+int vit_hip_export_planes(vit_hip_ctx *ctx, const char *path)
+{
+    int rc = 0;
+    if (!ctx || !path)
+        return vh_set_error(1, "vit_hip_export_planes: null argument");
+    TRY(vh_set_device(ctx->device));
+    FILE *fp = fopen(path, "wb");
+    if (!fp)
+        return vh_set_error(122, "vit_hip_export_planes: cannot open the file for writing");
+    struct planes_header h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "VITPLN01", 8);
+    h.header_bytes = (unsigned)sizeof(h);
+    h.precision = ctx->precision;
+    h.n_tensors = ctx->n_tensors;
+    const vit_config *c = &ctx->cfg;
+    const int ints[8] = {c->img_size, c->patch_size, c->in_chans, c->num_classes, c->embed_dim, c->depth, c->num_heads, c->mlp_hidden};
+    memcpy(h.cfg_ints, ints, sizeof(ints));
+    h.eps = c->eps;
+    h.w_slab_bytes = ctx->w_slab_bytes;
+    h.planes_bytes = ctx->planes_bytes;
+    h.wconv16_bytes = ctx->wconv16_bytes;
+    h.scale_floats = (unsigned long long)ctx->n_tensors;
+    if (fwrite(&h, sizeof(h), 1, fp) != 1 || fwrite(ctx->w3_scale, sizeof(float), (size_t)ctx->n_tensors, fp) != (size_t)ctx->n_tensors)
+        rc = vh_set_error(120, "vit_hip_export_planes: short write");
+    if (rc == 0)
+        rc = copy_file_and_device(ctx, fp, ctx->w_slab, ctx->w_slab_bytes, 1);
+    if (rc == 0)
+        rc = copy_file_and_device(ctx, fp, planes_slab(ctx), ctx->planes_bytes, 1);
+    if (rc == 0)
+        rc = copy_file_and_device(ctx, fp, ctx->wconv16, ctx->wconv16_bytes, 1);
+    if (fclose(fp) != 0 && rc == 0)
+        rc = vh_set_error(120, "vit_hip_export_planes: short write");
+    return rc;
+fail:
+    return rc;
+}
+
+int vit_hip_create_from_planes(vit_hip_ctx **out, const char *path, int device, int max_batch)
+{
+    int rc = 0;
+    if (!out)
+        return 1;
+    *out = NULL;
+    if (!path)
+        return vh_set_error(1, "vit_hip_create_from_planes: null path");
+    FILE *fp = fopen(path, "rb");
+    if (!fp)
+        return vh_set_error(123, "vit_hip_create_from_planes: cannot open the file");
+    struct planes_header h;
+    vit_hip_ctx *ctx = NULL;
+    if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, "VITPLN01", 8) != 0 || h.header_bytes != sizeof(h)) {
+        fclose(fp);
+        return vh_set_error(124, "vit_hip_create_from_planes: not a planes file of this library version");
     }
-
-    if (precision == VIT_PRECISION_F32_FP16X2) {
-        /* two fp16 parts of w * 2^k per weight (4 bytes), k per tensor such that max|w| * 2^k lands in
-         * [8192, 16384): the low part stays clear of fp16's subnormals, nothing overflows */
-        static const int big[4] = {2, 4, 8, 10};
-        size_t total3 = 0;
-        for (int l = 0; l < cfg->depth; ++l)
-            for (int k = 0; k < 4; ++k)
-                total3 += align_up(networks[4 + 12 * l + big[k]].size * 4, 256);
-        TRY(vh_malloc(&ctx->w3_slab, total3));
-        float *d_amax = NULL, amax = 0.0f;
-        TRY(vh_malloc((void **)&d_amax, sizeof(float)));
-        size_t off3 = 0;
-        for (int l = 0; l < cfg->depth && rc == 0; ++l)
-            for (int k = 0; k < 4 && rc == 0; ++k) {
-                const int idx = 4 + 12 * l + big[k];
-                const int out_f = (int)networks[idx + 1].size, in_f = (int)(networks[idx].size / networks[idx + 1].size);
-                if ((rc = vh_memset(d_amax, 0, sizeof(float), ctx->stream)) != 0 ||
-                    (rc = vh_launch_absmax(ctx->stream, ctx->w[idx], networks[idx].size, d_amax)) != 0 ||
-                    (rc = vh_d2h(&amax, d_amax, sizeof(float), ctx->stream)) != 0 ||
-                    (rc = vh_stream_sync(ctx->stream)) != 0)
-                    break;
-                int e = 0;
-                float scale = 1.0f;
-                if (amax > 0.0f && amax < 3.0e38f) {
-                    (void)frexpf(amax, &e);                 /* amax = m * 2^e, m in [0.5, 1) */
-                    scale = ldexpf(1.0f, 14 - e);           /* amax * scale in [8192, 16384) */
-                }
-                ctx->w3[idx] = (char *)ctx->w3_slab + off3;
-                ctx->w3_scale[idx] = scale;
-                rc = vh_launch_split2h_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], out_f, in_f, scale);
-                off3 += align_up(networks[idx].size * 4, 256);
-            }
-        vh_free(d_amax);
-        if (rc)
-            goto fail;
+    vit_config cfg = {h.cfg_ints[0], h.cfg_ints[1], h.cfg_ints[2], h.cfg_ints[3], h.cfg_ints[4], h.cfg_ints[5], h.cfg_ints[6],
+                      h.cfg_ints[7], h.eps};
+    if ((rc = ctx_new(&ctx, &cfg, h.n_tensors, device, max_batch, h.precision)) != 0) {
+        fclose(fp);
+        return vh_set_error(rc, "vit_hip_create_from_planes: the header's model shape or precision is not one this library takes");
     }
-
-    if (precision == VIT_PRECISION_FP8_GEMM) {
-        /* block-scaled fp8 copies of in_proj, out_proj, fc1, fc2: values (1 byte per weight) then the e8m0 scales
-         * (1 byte per 32 weights), both 256-byte aligned in one slab */
-        static const int big[4] = {2, 4, 8, 10};
-        size_t total8 = 0;
-        for (int l = 0; l < cfg->depth; ++l)
-            for (int k = 0; k < 4; ++k) {
-                const size_t cnt = networks[4 + 12 * l + big[k]].size;
-                total8 += align_up(cnt, 256) + align_up(cnt / 32, 256);
-            }
-        TRY(vh_malloc(&ctx->w8_slab, total8));
-        size_t off8 = 0;
-        for (int l = 0; l < cfg->depth; ++l)
-            for (int k = 0; k < 4; ++k) {
-                const int idx = 4 + 12 * l + big[k];
-                const size_t cnt = networks[idx].size;
-                const int out_f = (int)networks[idx + 1].size, in_f = (int)(cnt / networks[idx + 1].size);
-                ctx->w8[idx] = (char *)ctx->w8_slab + off8;
-                ctx->w8s[idx] = (char *)ctx->w8_slab + off8 + align_up(cnt, 256);
-                TRY(vh_launch_quantize_mx_rows(ctx->stream, ctx->w[idx], ctx->w8[idx], ctx->w8s[idx], out_f, in_f));
-                off8 += align_up(cnt, 256) + align_up(cnt / 32, 256);
-            }
+    if (h.scale_floats != (unsigned long long)ctx->n_tensors ||
+        fread(ctx->w3_scale, sizeof(float), (size_t)ctx->n_tensors, fp) != (size_t)ctx->n_tensors) {
+        rc = vh_set_error(124, "vit_hip_create_from_planes: truncated header");
+        goto fail;
     }
-
-    if ((precision == VIT_PRECISION_BF16_GEMM || precision == VIT_PRECISION_FP8_GEMM) && cfg->embed_dim % 128 == 0) {
-        /* the reduced modes' patch embedding: conv weights rounded to bf16 planes, K padded to the one-part K step */
-        const size_t kp = (size_t)vh_patch_planes_k(cfg->in_chans, cfg->patch_size);
-        TRY(vh_malloc(&ctx->wconv16, kp * (size_t)cfg->embed_dim * 2));
-        TRY(vh_launch_conv_weight_planes(ctx->stream, ctx->w[1], ctx->wconv16, cfg->embed_dim, cfg->in_chans, cfg->patch_size));
+    TRY(vh_init(device));
+    TRY(vh_stream_create(&ctx->stream));
+    TRY(layout_weights(ctx));
+    if (h.w_slab_bytes != ctx->w_slab_bytes || h.planes_bytes != ctx->planes_bytes || h.wconv16_bytes != ctx->wconv16_bytes) {
+        rc = vh_set_error(125, "vit_hip_create_from_planes: slab sizes in the file do not match this library's layout");
+        goto fail;
     }
+    TRY(copy_file_and_device(ctx, fp, ctx->w_slab, ctx->w_slab_bytes, 0));
+    TRY(copy_file_and_device(ctx, fp, planes_slab(ctx), ctx->planes_bytes, 0));
+    TRY(copy_file_and_device(ctx, fp, ctx->wconv16, ctx->wconv16_bytes, 0));
+    TRY(alloc_arena(ctx));
+    fclose(fp);
+    *out = ctx;
+    return 0;
+fail:
+    fclose(fp);
+    vit_hip_destroy(ctx);
+    return rc;
+}
 
+/* The activation arena and the host-pointer path's staging, sized for max_batch images. */
+static int alloc_arena(vit_hip_ctx *ctx)
+{
+    int rc = 0;
+    const vit_config *cfg = &ctx->cfg;
+    const int precision = ctx->precision, max_batch = ctx->max_batch;
     const size_t E = (size_t)cfg->embed_dim, F = (size_t)cfg->mlp_hidden, NC = (size_t)cfg->num_classes;
     const size_t rows = (size_t)max_batch * ctx->tokens;
     const size_t img = (size_t)cfg->in_chans * cfg->img_size * cfg->img_size;
@@ -430,10 +613,8 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
         TRY(vh_event_create(&ctx->out_done[i]));
     }
     TRY(vh_stream_sync(ctx->stream));
-    *out = ctx;
     return 0;
 fail:
-    vit_hip_destroy(ctx);
     return rc;
 }
 

@@ -34,6 +34,7 @@ EXPORTS = [
     "ViT_opencl", "vit_hip_last_call_seconds", "vit_hip_create", "vit_hip_destroy", "vit_hip_forward", "vit_hip_forward_device",
     "vit_hip_config", "vit_hip_stream", "vit_hip_max_batch", "vit_hip_weight", "vit_hip_read_tokens",
     "vit_hip_profile_enable", "vit_hip_profile_read", "vit_hip_profile_select", "vit_hip_create_ex", "vit_hip_precision",
+    "vit_hip_export_planes", "vit_hip_create_from_planes",
     "vh_patch_embed_workspace", "vh_launch_patch_embed_ws", "vh_patch_planes_k", "vh_launch_conv_weight_planes",
     "vh_launch_patch_embed_planes", "vh_launch_split3_planes", "vh_launch_linear_w3",
     "vh_launch_split2h_planes", "vh_launch_linear_h2", "vh_launch_attention_h2", "vh_launch_attention_f16",
@@ -193,6 +194,8 @@ def lib() -> C.CDLL:
     L.vit_hip_create.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i]
     L.vit_hip_create_ex.argtypes = [C.POINTER(voidp), C.POINTER(VitConfig), C.POINTER(Network), i, i, i, i]
     L.vit_hip_precision.argtypes = [voidp]
+    L.vit_hip_export_planes.argtypes = [voidp, C.c_char_p]
+    L.vit_hip_create_from_planes.argtypes = [C.POINTER(voidp), C.c_char_p, i, i]
     f = C.c_float
     L.vh_launch_absmax.argtypes = [voidp, voidp, sz, voidp]
     L.vit_hip_destroy.argtypes = [voidp]
@@ -334,6 +337,8 @@ class DeviceBuffer:
 class ViTHip:
     """Resident-weights context (vit_hip_create / forward / destroy)."""
 
+    PRECISIONS = {"f32": 0, "bf16": 1, "fp8": 2, "f32_fp16x2": 3}
+
     def __init__(self, cfg: VitConfig, weights: list[np.ndarray], device: int = 0, max_batch: int = 64,
                  precision: str = "f32"):
         self.cfg = cfg
@@ -342,10 +347,27 @@ class ViTHip:
         self.ctx = voidp()
         self.precision = precision
         rc = self.L.vit_hip_create_ex(C.byref(self.ctx), C.byref(cfg), networks(weights), len(weights),
-                                      device, max_batch, {"f32": 0, "bf16": 1, "fp8": 2, "f32_fp16x2": 3}[precision])
+                                      device, max_batch, self.PRECISIONS[precision])
         check(rc, "vit_hip_create_ex")
         self.max_batch = max_batch
         self.tokens = tokens(cfg)
+
+    @classmethod
+    def from_planes(cls, path, device: int = 0, max_batch: int = 64) -> "ViTHip":
+        """A context from ONE repacked-weights file (vit_hip_export_planes / vit_hip_create_from_planes)."""
+        self = cls.__new__(cls)
+        self.L, self._weights, self.ctx = lib(), None, voidp()
+        check(self.L.vit_hip_create_from_planes(C.byref(self.ctx), str(path).encode(), device, max_batch),
+              "vit_hip_create_from_planes")
+        self.L.vit_hip_config.restype = C.POINTER(VitConfig)
+        self.L.vit_hip_config.argtypes = [voidp]
+        self.cfg = VitConfig.from_buffer_copy(self.L.vit_hip_config(self.ctx).contents)
+        self.precision = {v: k for k, v in cls.PRECISIONS.items()}[self.L.vit_hip_precision(self.ctx)]
+        self.max_batch, self.tokens = max_batch, tokens(self.cfg)
+        return self
+
+    def export_planes(self, path) -> None:
+        check(self.L.vit_hip_export_planes(self.ctx, str(path).encode()), "vit_hip_export_planes")
 
     @property
     def stream(self):
