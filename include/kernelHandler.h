@@ -191,6 +191,11 @@ int vh_launch_attention_planes_f16(vh_stream_t s, const void *qkv_planes_f16, vo
  * (csrc/attention_h16.hip): qkv_planes_f16 as above -> fp32 rows [n_images*tokens][embed_dim]. */
 int vh_launch_attention_planes_f16_hd80(vh_stream_t s, const void *qkv_planes_f16, float *output, int n_images,
                                         int tokens, int embed_dim, int num_heads);
+/* ... writing the output projection's operand directly: output_kind 1 = one-part bf16 planes [embed_dim/32][rows][32], 2 =
+ * the block-scaled fp8 tensor (values + out_scales); the fp32 result followed by vh_launch_split_rows(parts = 1) /
+ * vh_launch_quantize_mx_rows, byte for byte.  head_dim 80, num_heads even, tokens <= 272. */
+int vh_launch_attention_planes_f16_hd80_operand(vh_stream_t s, const void *qkv_planes_f16, void *output, void *out_scales,
+                                                int output_kind, int n_images, int tokens, int embed_dim, int num_heads);
 /* vh_launch_linear on planes: input_planes [colA/32][3][rowA][32], weight_planes [colA/32][3][colB][32];
  * output fp32 [rowA][colB], or (output_planes != 0, no residual) planes [colB/32][3][rowA][32].
  * colA % 64 == 0, colB % 128 == 0. */

@@ -59,3 +59,19 @@ def test_bench_two_ranks_launch_themselves_verify_the_gather_and_report_the_cpu_
     assert out["checks"]["logits_finite"]
     lib_leg = out["in_library_multi_gpu"]          # the C-side RCCL entry, degenerate group of one on this box
     assert "error" not in lib_leg and lib_leg["devices"] == [0] and lib_leg["value"] > 0 and lib_leg["logits_finite"]
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_with_a_group_of_one():
+    """bench.py's RCCL-specific body -- logits in a torch tensor, forward on a torch side stream, dist.gather over the
+    nccl (= RCCL) backend enqueued on the same stream, barrier + device synchronise around the timed region -- with a
+    process group of ONE rank on the box's single card ($VIT_DIST_FORCE=1): everything the N > 1 launch does except a
+    second GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("VIT_DIST_BACKEND", "VIT_BENCH_DEVICE")}
+    env.update(VIT_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--no-cpu-baseline", "--no-in-library-multi"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["gather"]["backend"] == "rccl" and out["gather"]["rccl_ranks"] == 1
+    assert out["value"] > 0 and out["checks"]["logits_finite"] and abs(out["checks"]["prob_sum_image0"] - 1.0) < 1e-5

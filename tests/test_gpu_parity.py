@@ -749,6 +749,40 @@ def test_resident_fp16_planes_attention_for_head_dim_80(pkg, device, oracle, n_i
     assert L.vh_launch_attention_planes_f16_hd80(None, d_qh.ptr, d_c.ptr, n_images, tokens, 1024, H) != 0
 
 
+@pytest.mark.parametrize("n_images,tokens", [(2, 257), (1, 50), (40, 257), (1, 1)])
+def test_head_dim_80_attention_writing_the_next_operand_equals_rows_then_the_repack_byte_for_byte(pkg, device, oracle, n_images, tokens):
+    """vh_launch_attention_planes_f16_hd80_operand: ViT-H/14's attention writing the output projection's operand itself --
+    one-part bf16 planes, or the block-scaled fp8 tensor -- although head_dim 80 does not tile the formats' 32-column
+    blocks (a workgroup walks head pairs and carries the even head's last half block in registers).  Must equal the
+    fp32-rows kernel followed by vh_launch_split_rows(parts = 1) / vh_launch_quantize_mx_rows, byte for byte
+    (e4m3 zeros up to their sign)."""
+    E, H = 1280, 16
+    rows = n_images * tokens
+    qkv = oracle.synth_fill(rows * 3 * E, 1511 + tokens, 1.0, 0.0).reshape(rows, 3 * E)
+    planes = np.ascontiguousarray(qkv.astype(np.float16).reshape(rows, 3 * E // 32, 32).transpose(1, 0, 2))
+    d_qh = pkg.DeviceBuffer.from_numpy(planes.ravel().view(np.float32))
+    d_rows = pkg.DeviceBuffer(rows * E)
+    _launch(pkg, "vh_launch_attention_planes_f16_hd80", None, d_qh.ptr, d_rows.ptr, n_images, tokens, E, H)
+    nb = rows * E
+    # one-part bf16 planes
+    d_want, d_got = pkg.DeviceBuffer(nb // 2 + 4), pkg.DeviceBuffer(nb // 2 + 4)
+    _launch(pkg, "vh_launch_split_rows", None, d_rows.ptr, d_want.ptr, rows, E, 1)
+    _launch(pkg, "vh_launch_attention_planes_f16_hd80_operand", None, d_qh.ptr, d_got.ptr, None, 1, n_images, tokens, E, H)
+    assert np.array_equal(d_got.to_numpy().view(np.uint16)[:nb], d_want.to_numpy().view(np.uint16)[:nb])
+    # block-scaled fp8
+    d_wv, d_ws = pkg.DeviceBuffer(nb // 4 + 4), pkg.DeviceBuffer(nb // 128 + 4)
+    d_gv, d_gs = pkg.DeviceBuffer(nb // 4 + 4), pkg.DeviceBuffer(nb // 128 + 4)
+    _launch(pkg, "vh_launch_quantize_mx_rows", None, d_rows.ptr, d_wv.ptr, d_ws.ptr, rows, E)
+    _launch(pkg, "vh_launch_attention_planes_f16_hd80_operand", None, d_qh.ptr, d_gv.ptr, d_gs.ptr, 2, n_images, tokens, E, H)
+    wv, gv = d_wv.to_numpy().view(np.uint8)[:nb], d_gv.to_numpy().view(np.uint8)[:nb]
+    assert np.array_equal(d_gs.to_numpy().view(np.uint8)[:nb // 32], d_ws.to_numpy().view(np.uint8)[:nb // 32])
+    zero = (wv & 0x7f) == 0
+    assert np.array_equal(gv[~zero], wv[~zero]) and np.array_equal(gv[zero] & 0x7f, wv[zero] & 0x7f)
+    L = pkg.lib()
+    assert L.vh_launch_attention_planes_f16_hd80_operand(None, d_qh.ptr, d_got.ptr, None, 1, n_images, tokens, 1200, 15) != 0   # odd head count
+    assert L.vh_launch_attention_planes_f16_hd80_operand(None, d_qh.ptr, d_gv.ptr, None, 2, n_images, tokens, E, H) != 0        # no scales
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16", "fp8", "f32_fp16x2"])
 def test_repacked_weights_file_round_trip_is_bit_identical(pkg, device, weights, tmp_path, precision):
     """vit_hip_export_planes / vit_hip_create_from_planes (the offline repack; the reference's loader reads

@@ -658,8 +658,10 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
             OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16_mx(s, ctx->qkv, ctx->attn, as_, n, T, E, c->num_heads));
         } else if (E == 80 * c->num_heads && T <= 272) {   /* ViT-H/14: fp16 planes in, K and V resident in LDS, fp32 rows out */
             OP(VIT_OP_QKV, vh_launch_linear_mx_planes_f16(s, ctx->qkv, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E));
-            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                                 vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
+            OP(VIT_OP_ATTENTION, (c->num_heads & 1) == 0
+                   ? vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, as_, 2, n, T, E, c->num_heads)   /* writes the MX tensor itself */
+                   : (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                     vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
         } else {
             OP(VIT_OP_QKV, vh_launch_linear_mx(s, ctx->qkv, NULL, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E, 0, NULL));
             OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
@@ -694,8 +696,10 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
             OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16(s, ctx->qkv, ctx->attn, 1, n, T, E, c->num_heads));
         } else if (E == 80 * c->num_heads && T <= 272) {   /* ViT-H/14: fp16 planes in, K and V resident in LDS, fp32 rows out */
             OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 2, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
-            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                                 vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
+            OP(VIT_OP_ATTENTION, (c->num_heads & 1) == 0
+                   ? vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, NULL, 1, n, T, E, c->num_heads)  /* writes the planes itself */
+                   : (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                     vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
         } else {   /* other shapes of the streaming attention kernel: fp32 output (into the idle MLP buffer), then rounded into planes */
             OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 0, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
             OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :

@@ -18,8 +18,15 @@
  *    three planes p0 .. p0+2 are staged and every 16-wide d group g sits in plane (g + sh) >> 1, half (g + sh) & 1;
  *  - K fragment (16 keys x 4 d per lane group): ds_read_b64 from rows whose 16-byte chunks carry gemm_common.h's
  *    swz64 (conflict-free); V fragment (16 d x 4 keys): ds_read_b64_tr_b16 from linear rows, one per MFMA.
- * Output: fp32 rows [rows][E] (the caller quantises / rounds them into the next GEMM's operand: head_dim 80 does not
- * tile the 32-column blocks of those formats).
+ * Output: fp32 rows [rows][E] (OUTK 0), or the output projection's operand directly -- one-part bf16 planes (OUTK 4) or
+ * the block-scaled fp8 tensor (OUTK 8).  head_dim 80 does not tile those formats' 32-column blocks: columns 64-79 of an
+ * even head share a block with columns 0-15 of the next head.  For those outputs a workgroup therefore walks head
+ * PAIRS (2k, 2k+1) back to back -- the K / V hand-over pipeline does not care -- and a lane keeps its four values of
+ * the even head's last 16 columns in registers (the same lane holds the same query's columns in the odd head: the
+ * tile -> wave map does not depend on the head) until the odd head's first 16 arrive; every block then has its 32
+ * values in the four lanes of one query, as the scale needs.  Same values as the fp32 rows followed by
+ * vh_launch_quantize_mx_rows / vh_launch_split_rows(parts = 1), byte for byte, without the 2 x 4-byte round trip of
+ * every output value through HBM.
  */
 #include "kernelHandler.h"
 #include "vit_kernels.h"
@@ -46,10 +53,14 @@ __device__ __forceinline__ half4 to_half4(const f32x4 &v)
     return h;
 }
 
-template <int HD, int NJ, int NW> /* NJ 16-key tiles (T <= 16 NJ), NW waves; two rounds of NW 16-query tiles cover T <= 32 NW */
+template <int HD, int NJ, int NW, int OUTK> /* NJ 16-key tiles (T <= 16 NJ), NW waves; two rounds of NW 16-query tiles cover T <= 32 NW */
 __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__restrict__ qkvh, float *__restrict__ out,
+                                                               unsigned char *__restrict__ out_scales,
                                                                int T, int E, int H, int n_items, float scale_log2e)
 {
+    constexpr bool PAIRS = OUTK != 0;               /* walk head pairs (H even): blocks that straddle two heads */
+    static_assert(OUTK == 0 || OUTK == 4 || OUTK == 8, "output kind");
+    static_assert(!PAIRS || HD == 80, "the carried half block is written for head_dim 80");
     constexpr int G = HD / 16;                      /* 16-wide d groups */
     constexpr int PLN = (HD + 16 + 31) / 32;        /* planes staged per operand (any 16-column offset of the head) */
     constexpr int RB = 16 * NJ;                     /* rows per staged plane */
@@ -86,16 +97,25 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
         kofs[hf] = l15 * 64 + 16 * ((2 * hf + (g >> 1)) ^ swz64(l15 >> 2)) + 8 * (g & 1);
     const int vrow = (4 * g + (l15 >> 2)) * 64 + 8 * (l15 & 3);     /* transposed read: lane i addresses row i >> 2, columns 4 (i & 3) .. */
 
-    int item = blockIdx.x;
+    /* the workgroup's n-th item: (image, head) number blockIdx.x + n gridDim.x, or -- PAIRS -- head n & 1 of its
+     * (n >> 1)-th head pair; n_items beyond the end */
+    auto nth_item = [&](int n) -> int {
+        if (!PAIRS)
+            return min((int)blockIdx.x + n * (int)gridDim.x, n_items);
+        const int pair = (int)blockIdx.x + (n >> 1) * (int)gridDim.x;
+        return pair < (n_items >> 1) ? 2 * pair + (n & 1) : n_items;
+    };
+    int n = 0, item = nth_item(0);
     if (item >= n_items)
         return;
     dma(item, 1, Kb);
     __syncthreads();                                     /* K of the first item */
 
-    for (; item < n_items; item += gridDim.x) {
+    f32x4 carry[2] = {};                                 /* PAIRS: columns 64..79 of the even head, per round */
+    for (; item < n_items; item = nth_item(++n)) {
         const int b = item / H, h = item - b * H;
         const int c0 = HD * h, p0 = c0 >> 5, sh = (c0 >> 4) & 1;
-        const int next = item + gridDim.x;
+        const int next = nth_item(n + 1);
         dma(item, 2, Vb);                                /* Vb is free: every wave finished P.V of the previous item */
 
 #pragma unroll
@@ -182,11 +202,55 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
                     }
                 }
                 /* O^T register r of d group dt: d = 16dt + 4g + r, query = lane & 15 */
-                if (q_row < T) {
-                    float *o = out + ((size_t)b * T + q_row) * E + (size_t)c0 + 4 * g;
+                if (OUTK == 0) {
+                    if (q_row < T) {
+                        float *o = out + ((size_t)b * T + q_row) * E + (size_t)c0 + 4 * g;
 #pragma unroll
-                    for (int dt = 0; dt < G; ++dt)
-                        *reinterpret_cast<f32x4 *>(o + 16 * dt) = O[dt];
+                        for (int dt = 0; dt < G; ++dt)
+                            *reinterpret_cast<f32x4 *>(o + 16 * dt) = O[dt];
+                    }
+                } else {
+                    /* 32-column blocks of this head: even head (sh = 0): (dt 0, 1), (dt 2, 3), dt 4 is carried; odd head:
+                     * (carry, dt 0), (dt 1, 2), (dt 3, 4).  A block's two halves sit at positions 4g + r and 16 + 4g + r
+                     * of its row; the four lanes l15 + 16 g of a query hold the block. */
+                    const size_t orow = (size_t)b * T + min(q_row, T - 1);
+                    auto emit = [&](const f32x4 &lo, const f32x4 &hi, int col /* first column of the block */) {
+                        if (OUTK == 4) {
+                            if (q_row < T) {
+                                typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                                char *d = reinterpret_cast<char *>(out) + ((size_t)(col >> 5) * prow + orow) * 64 + 8 * g;
+                                *reinterpret_cast<bf16x4_t *>(d) = bf16x4_t{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3]};
+                                *reinterpret_cast<bf16x4_t *>(d + 32) = bf16x4_t{(__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+                            }
+                        } else {
+                            float amax = 0.0f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                amax = fmaxf(amax, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+                            amax = fmaxf(amax, __shfl_xor(amax, 16));
+                            amax = fmaxf(amax, __shfl_xor(amax, 32));
+                            unsigned sbyte;
+                            float mult;
+                            mx_block_scale(amax, sbyte, mult);
+                            if (q_row < T) {
+                                const int ks = col >> 7, blk = (col >> 5) & 3;
+                                char *d = reinterpret_cast<char *>(out) + ((size_t)ks * prow + orow) * 128 + 32 * blk + 4 * g;
+                                *reinterpret_cast<unsigned *>(d) = pack_fp8x4(lo * mult);
+                                *reinterpret_cast<unsigned *>(d + 16) = pack_fp8x4(hi * mult);
+                                if (g == 0)   /* scales[ks][lane group of block blk][row]: block b is read by lane group 2 (b & 1) + (b >> 1) */
+                                    out_scales[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * prow + orow] = (unsigned char)sbyte;
+                            }
+                        }
+                    };
+                    if (sh == 0) {
+                        emit(O[0], O[1], c0);
+                        emit(O[2], O[3], c0 + 32);
+                        carry[rnd] = O[4];
+                    } else {
+                        emit(carry[rnd], O[0], c0 - 16);
+                        emit(O[1], O[2], c0 + 16);
+                        emit(O[3], O[4], c0 + 48);
+                    }
                 }
             }
         }
@@ -194,17 +258,19 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
     }
 }
 
-template <int HD, int NJ, int NW>
-int launch_h16(hipStream_t st, const char *qkvh, float *out, int n_images, int T, int E, int H)
+template <int HD, int NJ, int NW, int OUTK>
+int launch_h16(hipStream_t st, const char *qkvh, void *out, void *out_scales, int n_images, int T, int E, int H)
 {
     constexpr int PLN = (HD + 16 + 31) / 32;
     const size_t lds = (size_t)2 * PLN * 16 * NJ * 64;
-    VH_SET_LDS_ONCE((attention_h16_kernel<HD, NJ, NW>), MAX_LDS);
+    VH_SET_LDS_ONCE((attention_h16_kernel<HD, NJ, NW, OUTK>), MAX_LDS);
     const int num_cus = vh_device_cus(vh_current_device());
     const int n_items = n_images * H;
-    const int grid = n_items < num_cus ? n_items : num_cus;
+    const int units = OUTK ? n_items / 2 : n_items;      /* workgroups walk head pairs when blocks straddle heads */
+    const int grid = units < num_cus ? units : num_cus;
     const float c = 1.4426950408889634f / sqrtf((float)HD);
-    hipLaunchKernelGGL((attention_h16_kernel<HD, NJ, NW>), dim3(grid), dim3(64 * NW), lds, st, qkvh, out, T, E, H, n_items, c);
+    hipLaunchKernelGGL((attention_h16_kernel<HD, NJ, NW, OUTK>), dim3(grid), dim3(64 * NW), lds, st, qkvh, static_cast<float *>(out),
+                       static_cast<unsigned char *>(out_scales), T, E, H, n_items, c);
     VH_LAUNCH_CHECK("attention_h16_kernel");
     return 0;
 }
@@ -223,6 +289,26 @@ extern "C" int vh_launch_attention_planes_f16_hd80(vh_stream_t s, const void *qk
                        n_images, tokens, embed_dim, num_heads);
     if ((((uintptr_t)qkv_planes_f16 | (uintptr_t)output) & 15) != 0)
         return vh_fail(1, "vh_launch_attention_planes_f16_hd80: pointers must be 16-byte aligned");
-    return launch_h16<80, 17, 9>((hipStream_t)s, static_cast<const char *>(qkv_planes_f16), output, n_images, tokens, embed_dim,
-                                 num_heads);
+    return launch_h16<80, 17, 9, 0>((hipStream_t)s, static_cast<const char *>(qkv_planes_f16), output, nullptr, n_images, tokens,
+                                    embed_dim, num_heads);
+}
+
+/* The same attention writing the output projection's operand directly: output_kind 1 = one-part bf16 planes
+ * [embed_dim/32][rows][32] (vh_launch_split_rows(parts = 1) of the fp32 result, byte for byte), 2 = the block-scaled fp8
+ * tensor (values [embed_dim/128][rows][128] + out_scales [embed_dim/128][4][rows]: vh_launch_quantize_mx_rows of the
+ * fp32 result, byte for byte).  num_heads even (blocks straddle head pairs); embed_dim % 128 == 0 for kind 2. */
+extern "C" int vh_launch_attention_planes_f16_hd80_operand(vh_stream_t s, const void *qkv_planes_f16, void *output, void *out_scales,
+                                                           int output_kind, int n_images, int tokens, int embed_dim, int num_heads)
+{
+    if (!qkv_planes_f16 || !output || (output_kind == 2 && !out_scales))
+        return vh_fail(1, "vh_launch_attention_planes_f16_hd80_operand: null pointer argument");
+    if (n_images <= 0 || tokens <= 0 || num_heads <= 0 || (num_heads & 1) || embed_dim != num_heads * 80 || tokens > 272 ||
+        (output_kind != 1 && output_kind != 2) || (output_kind == 2 && embed_dim % 128 != 0))
+        return vh_fail(1, "vh_launch_attention_planes_f16_hd80_operand: needs head_dim 80, an even number of heads, 1 <= tokens <= 272, "
+                          "output_kind 1 or 2 (n=%d tokens=%d embed=%d heads=%d kind=%d)", n_images, tokens, embed_dim, num_heads, output_kind);
+    if ((((uintptr_t)qkv_planes_f16 | (uintptr_t)output) & 15) != 0)
+        return vh_fail(1, "vh_launch_attention_planes_f16_hd80_operand: pointers must be 16-byte aligned");
+    const char *in = static_cast<const char *>(qkv_planes_f16);
+    return output_kind == 1 ? launch_h16<80, 17, 9, 4>((hipStream_t)s, in, output, nullptr, n_images, tokens, embed_dim, num_heads)
+                            : launch_h16<80, 17, 9, 8>((hipStream_t)s, in, output, out_scales, n_images, tokens, embed_dim, num_heads);
 }

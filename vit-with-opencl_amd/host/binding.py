@@ -44,7 +44,7 @@ EXPORTS = [
     "vh_launch_attention_planes_bf16", "vh_launch_linear_planes", "vh_launch_attention_planes",
     "vh_launch_quantize_mx_rows", "vh_launch_linear_mx", "vh_launch_layer_norm_mx",
     "vh_launch_attention_planes_f16", "vh_launch_linear_mx_planes_f16", "vh_launch_attention_planes_f16_mx",
-    "vh_launch_attention_planes_f16_hd80",
+    "vh_launch_attention_planes_f16_hd80", "vh_launch_attention_planes_f16_hd80_operand",
     "vh_launch_gather_rows", "vit_hip_set_last_layer_cls_only",
     "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
     "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run", "vit_hip_forward_device_multi", "vit_hip_device", "vh_set_error",
@@ -177,6 +177,7 @@ def lib() -> C.CDLL:
     L.vh_launch_attention_planes_f16.argtypes = [voidp, voidp, voidp, i, i, i, i, i]
     L.vh_launch_attention_planes_f16_mx.argtypes = [voidp, voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_attention_planes_f16_hd80.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_attention_planes_f16_hd80_operand.argtypes = [voidp, voidp, voidp, voidp, i, i, i, i, i]
     L.vh_launch_linear_mx_planes_f16.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, voidp, i, i, i]
     L.vh_launch_quantize_mx_rows.argtypes = [voidp, voidp, voidp, voidp, i, i]
     L.vh_launch_layer_norm_mx.argtypes = [voidp] + [voidp] * 5 + [i, i, C.c_long, C.c_double]
