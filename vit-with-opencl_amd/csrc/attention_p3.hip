@@ -336,6 +336,7 @@ int launch_k(hipStream_t st, const char *qkv3, char *out3, unsigned char *out_sc
     return 0;
 }
 
+
 template <int NPL, int OUTK>
 int launch_t(hipStream_t st, const char *in, char *out, unsigned char *out_scales, int n_images, int tokens, int embed_dim, int num_heads)
 {
