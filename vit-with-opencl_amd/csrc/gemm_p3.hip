@@ -345,10 +345,11 @@ int launch_p3(hipStream_t st, const P3Params &p, int small_only)
     const int num_cus = vh_device_cus(vh_current_device());
     const int ntiles = p.N / 256, mtiles = (rows + 255) / 256;
     const long tiles = (long)mtiles * ntiles;
-    /* One-part operands with the residual epilogue (the reduced modes' output projection and fc2): 128x256 tiles, 4
-     * waves of 32x256, two workgroups per CU -- one workgroup's stores of fp32 rows run under the other's K loop
-     * (measured, ViT-B/16 batch 512: out-proj 0.223 -> 0.213 ms, fc2 0.503 -> 0.491 against the rule below). */
-    if (EPI == EPI_RESID && NPL == 1 && p.N % 256 == 0 && tiles >= num_cus)
+    /* One-part operands writing fp32 rows (the reduced modes' output projection, fc2 and patch embedding): 128x256
+     * tiles, 4 waves of 32x256, two workgroups per CU -- one workgroup's stores of fp32 rows run under the other's K
+     * loop (measured, ViT-B/16 batch 512: out-proj 0.223 -> 0.213 ms, fc2 0.503 -> 0.491, patch embedding 0.29 -> 0.27
+     * against the rule below; the planes-out epilogues of QKV and fc1 measure the same either way). */
+    if ((EPI == EPI_RESID || EPI == EPI_PATCH) && NPL == 1 && p.N % 256 == 0 && tiles >= num_cus)
         return launch_p3_tile<4, 256, EPI, OUTK, NPL>(st, p);
     if (p.N % 256 != 0 || small_only || 2 * tiles < 5 * (long)num_cus)
         return launch_p3_tile<4, 128, EPI, OUTK, NPL>(st, p);
