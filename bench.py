@@ -140,6 +140,21 @@ def cpu_baseline(batch: int, n_procs: int):
                 {0: logits0})
 
 
+def committed_traffic(root: Path):
+    """(bytes per fc1 launch, where from, stale?) from the newest profiles/rNN_pmc_traffic.json -- withheld (None, ..., True)
+    when csrc/gemm_p3.hip is no longer the file the PMC passes were taken on (sha256 stored by tools/pmc_traffic.py)."""
+    import hashlib
+    pmcs = sorted((root / "profiles").glob("r*_pmc_traffic.json"))
+    if not pmcs:
+        return None, None, None
+    rec = json.loads(pmcs[-1].read_text())
+    sha_now = hashlib.sha256((root / "vit-with-opencl_amd" / "csrc" / "gemm_p3.hip").read_bytes()).hexdigest()
+    stale = rec.get("kernel_source_sha256") != sha_now
+    src = f"profiles/{pmcs[-1].name} (rocprofv3 --pmc passes, B=512; kernel source sha256 " \
+          f"{str(rec.get('kernel_source_sha256'))[:16]}, git {str(rec.get('git_head'))[:12]})"
+    return (None if stale else rec["traffic_bytes_per_launch"]), src, stale
+
+
 def spawn_ranks(n: int) -> int:
     """Start `n` ranks of this script under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) as a child
     process and wait for it.  Called before anything in this process has initialised the GPU; nothing is re-exec'd."""
@@ -583,15 +598,8 @@ def main() -> None:
         # The committed figure is tied to the kernel source it was measured on: tools/pmc_traffic.py stores the sha256
         # of csrc/gemm_p3.hip; when the file has changed since, the figure is withheld and marked stale.
         traffic, traffic_src, traffic_stale = None, None, None
-        pmcs = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
-        if pmcs and B == 512 and args.model == "vit_b_16" and p3:
-            import hashlib
-            rec = json.loads(pmcs[-1].read_text())
-            sha_now = hashlib.sha256((ROOT / "vit-with-opencl_amd" / "csrc" / "gemm_p3.hip").read_bytes()).hexdigest()
-            traffic_stale = rec.get("kernel_source_sha256") != sha_now
-            traffic = None if traffic_stale else rec["traffic_bytes_per_launch"]
-            traffic_src = f"profiles/{pmcs[-1].name} (rocprofv3 --pmc passes, B=512; kernel source sha256 " \
-                          f"{str(rec.get('kernel_source_sha256'))[:16]}, git {str(rec.get('git_head'))[:12]})"
+        if B == 512 and args.model == "vit_b_16" and p3:
+            traffic, traffic_src, traffic_stale = committed_traffic(ROOT)
         rows = B * tokens
         if p3:     # operands and result as three bf16 parts: 6 bytes per value
             alg_bytes = (rows * (cfg.embed_dim + cfg.mlp_hidden) + cfg.mlp_hidden * cfg.embed_dim) * 6

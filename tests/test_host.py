@@ -3,6 +3,7 @@ synthetic-data determinism, loaders, sharding.  No compute calls (no GPU here)."
 import ctypes as C
 import os
 import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -341,3 +342,52 @@ def test_mx_reference_scale_rule_layout_and_torch_cross_check():
     assert np.array_equal(q[~zero], want[~zero]) and np.array_equal(q[zero] & 0x7f, want[zero] & 0x7f)
     back = mx_ref.dequantize(values, scales).reshape(rows, cols // 32, 32)
     assert (np.abs(back - blocks) <= 2.0 ** -4 * np.maximum(amax, 2.0 ** -126)[:, :, None] * 1.0000001).all()
+
+
+def test_bench_traffic_figure_is_withheld_when_the_kernel_source_changed(tmp_path):
+    """bench.py's roofline.traffic comes from committed PMC passes; the record carries the sha256 of csrc/gemm_p3.hip and
+    the figure is reported only while that file is unchanged (the committed record must match the committed source)."""
+    import hashlib
+    import importlib
+    import json
+    import shutil
+    bench = importlib.import_module("bench")
+    traffic, src, stale = bench.committed_traffic(ROOT)
+    assert stale is False and traffic and traffic > 2.3e9 and "pmc_traffic.json" in src, \
+        "profiles/rNN_pmc_traffic.json is out of date: re-run tools/pmc_passes.sh + tools/pmc_traffic.py"
+    fake = tmp_path / "repo"
+    (fake / "profiles").mkdir(parents=True)
+    (fake / "vit-with-opencl_amd" / "csrc").mkdir(parents=True)
+    newest = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
+    shutil.copy(newest, fake / "profiles" / newest.name)
+    kernel = (ROOT / "vit-with-opencl_amd" / "csrc" / "gemm_p3.hip").read_text()
+    (fake / "vit-with-opencl_amd" / "csrc" / "gemm_p3.hip").write_text(kernel)
+    assert bench.committed_traffic(fake)[2] is False
+    (fake / "vit-with-opencl_amd" / "csrc" / "gemm_p3.hip").write_text(kernel + "\n/* edited */\n")
+    assert bench.committed_traffic(fake) [0] is None and bench.committed_traffic(fake)[2] is True
+    rec = json.loads(newest.read_text())
+    assert rec["kernel_source_sha256"] == hashlib.sha256(kernel.encode()).hexdigest()
+
+
+def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: torch.distributed.run as a CHILD process (nothing re-exec'd),
+    rendezvous on 127.0.0.1, the caller's arguments passed through, dmabuf IPC kept in the environment."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.spawn_ranks(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
