@@ -398,3 +398,17 @@ def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_drop_in_with_zero_images_returns_without_a_device(pkg, capfd):
+    """image[0].n == 0: the reference's per-image loop does not run (ViT_opencl.c:926).  The drop-in returns at once --
+    on this GPU-less container any device call would have exited the process (VH_CHECK)."""
+    b, L = pkg.binding, pkg.lib()
+    img = (b.ImageData * 1)()
+    img[0].n, img[0].c, img[0].h, img[0].w = 0, 3, 224, 224
+    nets = (b.Network * 152)()
+    rows = (b.f32p * 1)()
+    L.ViT_opencl(img, nets, rows)
+    su, fw = C.c_double(-1), C.c_double(-1)
+    L.vit_hip_last_call_seconds(C.byref(su), C.byref(fw))
+    assert su.value == 0.0 and fw.value == 0.0

@@ -1191,6 +1191,11 @@ void ViT_opencl(ImageData *image, Network *networks, float **probabilities)
     vit_config cfg;
     vit_config_preset(&cfg, "vit_b_16");
     const int n = image[0].n;
+    if (n <= 0) {   /* the reference's per-image loop simply does not run (ViT_opencl.c:926); no device is touched */
+        printf("setup time: 0.000000 sec (no images)\n\n");
+        last_setup_s = last_forward_s = 0.0;
+        return;
+    }
     int device = 0;
     const char *env = getenv("VIT_HIP_DEVICE");
     if (env && *env)
