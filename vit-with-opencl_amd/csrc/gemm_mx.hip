@@ -55,7 +55,11 @@ struct MxParams {
     int row_begin, row_end, N, K, a_rows, mtiles, ntiles;
 };
 
-template <int NW, int BN, int EPI, int OUTK>
+/* LAB (tools/mx_lab.hip only; 0 in the library): bit 1 skips the W DMA after the prologue, bit 2 the A loads after the
+ * prologue, bit 0 (only together with those two: alone it trips the compiler) the W fragment reads after the first step,
+ * bit 3 the A scale-byte loads after the prologue (values still loaded), bit 6 drops the epilogue's stores -- throw-away
+ * ablations that price each data movement; their results are wrong by construction. */
+template <int NW, int BN, int EPI, int OUTK, int LAB = 0>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
 {
     constexpr int BM = 32 * NW, JT = BN / 16, RING = 4;
@@ -146,7 +150,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
         for (int i = 0; i < 2; ++i) {
             al[i] = __builtin_bit_cast(i32x4, *reinterpret_cast<gvec_t>(vb + aoff[i]));
             ah[i] = __builtin_bit_cast(i32x4, *reinterpret_cast<gvec_t>(vb + aoff[i] + 32));
-            as[i] = sb[arow[i]];
+            if (!(LAB & 8) || kt == 0)
+                as[i] = sb[arow[i]];
         }
     };
     auto read_w = [&](int slot, const char *stage, int j) {
@@ -177,19 +182,22 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
     auto step = [&](const i32x4 (&ul)[2], const i32x4 (&uh)[2], const int (&us)[2], i32x4 (&nl)[2], i32x4 (&nh)[2], int (&ns)[2], int kt) {
         const char *cur = smem + (kt & 1) * STAGE, *nxt = smem + ((kt + 1) & 1) * STAGE;
         const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-        load_a(nl, nh, ns, more1 ? kt + 1 : kt);   /* unconditional (no copies at a join): the last step re-reads its own */
+        if (!(LAB & 4))
+            load_a(nl, nh, ns, more1 ? kt + 1 : kt);   /* unconditional (no copies at a join): the last step re-reads its own */
 #pragma unroll
         for (int f = 0; f <= JT - RING; ++f) {
             mfma_frag(ul, uh, us, f % RING, f);
-            read_w((f + RING - 1) % RING, cur, f + RING - 1);   /* the slot fragment f-1 was in */
+            if (!(LAB & 1) || kt == 0)
+                read_w((f + RING - 1) % RING, cur, f + RING - 1);   /* the slot fragment f-1 was in */
         }
         __syncthreads();   /* stage kt read by every wave (its last fragments are in registers); stage kt+1 has landed */
-        if (more2)
+        if (more2 && !(LAB & 2))
             dma_w(kt & 1, kt + 2);
 #pragma unroll
         for (int f = JT - RING + 1; f < JT; ++f) {
             mfma_frag(ul, uh, us, f % RING, f);
-            read_w((f + RING - 1) % RING, nxt, f + RING - 1 - JT);   /* unconditional: behind the last step it reads a stage nobody uses */
+            if (!(LAB & 1) || kt == 0)
+                read_w((f + RING - 1) % RING, nxt, f + RING - 1 - JT);   /* unconditional: behind the last step it reads a stage nobody uses */
         }
     };
 
@@ -203,7 +211,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
         read_w(f, smem, f);
     for (int kt = 0; kt < nk; kt += 2) {   /* nk is even (launcher) */
         step(a0l, a0h, a0s, a1l, a1h, a1s, kt);
-        step(a1l, a1h, a1s, a0l, a0h, a0s, kt + 1);
+        if (LAB & 4)
+            step(a0l, a0h, a0s, a1l, a1h, a1s, kt + 1);
+        else
+            step(a1l, a1h, a1s, a0l, a0h, a0s, kt + 1);
     }
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   /* the last MFMA's result, before ordinary code reads it */
@@ -236,7 +247,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
                 unsigned sbyte;
                 float mult;
                 mx_block_scale(amax, sbyte, mult);
-                if (live) {
+                if (LAB & 64) {
+                    asm volatile("" ::"v"(lo), "v"(hi), "v"(mult), "v"(sbyte));
+                } else if (live) {
                     const int ks = (n0 + 32 * s) >> 7, blk = ((n0 + 32 * s) >> 5) & 3;
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     *reinterpret_cast<u32x2 *>(static_cast<char *>(p.C) + ((size_t)ks * p.a_rows + row) * 128 + 32 * blk + 8 * j4) =
@@ -254,6 +267,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
                     *reinterpret_cast<f32x4 *>(static_cast<char *>(p.C) + ((size_t)(col >> 5) * p.a_rows + row) * 64 + 16 * j4) =
                         __builtin_bit_cast(f32x4, hv);
                 }
+            } else if (LAB & 64) {
+                asm volatile("" ::"v"(lo), "v"(hi));
             } else if (live) {
                 float *cp = static_cast<float *>(p.C) + (size_t)row * p.N + col;
                 *reinterpret_cast<f32x4 *>(cp) = lo;
