@@ -247,6 +247,9 @@ int main(int argc, char **argv)
         {"A and W of tile 0 everywhere   ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 48>},
         {"no epilogue stores             ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64>},
         {"no stores, no reads/DMA/A loads", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64 + 7>},
+        {"128x128 tiles (fc1: GELU, planes) ", launch_variant<4, 128, EPI_GELU, OUT_PLANES, 0>},
+        {"256x256, no GELU, planes out (QKV)", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 0>},
+        {"128x128, no GELU, planes out (QKV)", launch_variant<4, 128, EPI_NONE, OUT_PLANES, 0>},
         {"32x32x16 MFMA (fc1: GELU, planes)", launch_m32<EPI_GELU, OUT_PLANES, 0>},
         {"32x32x16 MFMA, no stores         ", launch_m32<EPI_GELU, OUT_PLANES, 64>},
         {"32x32x16 MFMA, no GELU, fp32 out ", launch_m32<EPI_NONE, OUT_F32, 0>},
@@ -322,6 +325,25 @@ int main(int argc, char **argv)
             {"128x128, none of those, no stores", launch_variant<4, 128, EPI_NONE, OUT_F32, 64 + 7, 1>},
             {"256x256, no residual read        ", launch_variant<8, 256, EPI_NONE, OUT_F32, 0, 1>},
             {"256x256, no stores               ", launch_variant<8, 256, EPI_RESID, OUT_F32, 64, 1>},
+        };
+    }
+    if (argc >= 6 && parts == 3) {   /* "resid", three parts: the fp32 path's out-projection / fc2 (residual added to the finished sum) */
+        float *xres;
+        CK(hipMalloc(&xres, (size_t)M * N * 4));
+        fill_random<<<(unsigned)(((size_t)M * N + 255) / 256), 256, 0, st>>>(xres, (size_t)M * N, 4u, 1.0f);
+        p.R = xres; p.C = xres;
+        vs = {
+            {"128x128 tiles, + residual        ", launch_variant<4, 128, EPI_RESID, OUT_F32, 0>},
+            {"256x256 tiles, + residual        ", launch_variant<8, 256, EPI_RESID, OUT_F32, 0>},
+            {"128x128, no residual read        ", launch_variant<4, 128, EPI_NONE, OUT_F32, 0>},
+            {"128x128, no stores               ", launch_variant<4, 128, EPI_RESID, OUT_F32, 64>},
+            {"128x128, no resid read, no stores", launch_variant<4, 128, EPI_NONE, OUT_F32, 64>},
+            {"128x128, no A loads              ", launch_variant<4, 128, EPI_RESID, OUT_F32, 4>},
+            {"128x128, no W DMA                ", launch_variant<4, 128, EPI_RESID, OUT_F32, 2>},
+            {"128x128, no A/DMA/W reads        ", launch_variant<4, 128, EPI_RESID, OUT_F32, 7>},
+            {"128x128, none of those, no stores", launch_variant<4, 128, EPI_NONE, OUT_F32, 64 + 7>},
+            {"256x256, no residual read        ", launch_variant<8, 256, EPI_NONE, OUT_F32, 0>},
+            {"256x256, no stores               ", launch_variant<8, 256, EPI_RESID, OUT_F32, 64>},
         };
     }
     const int ROUNDS = 4, REPS = 10;
