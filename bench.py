@@ -100,7 +100,8 @@ def cpu_baseline(batch: int, n_procs: int):
     """Time the CPU path on this box.  Returns (dict for the JSON line, {image index: logits})."""
     harness = ROOT / "oracle" / "_ref" / "ref_harness"
     info = host_cpu_info()
-    n_procs = n_procs or info["usable_cores"]
+    # one image per usable core, at most 32 at once: a bounded sample (~6 s of wall, < 12 GB of host memory) on any node
+    n_procs = n_procs or min(info["usable_cores"], 32)
     # the parity images first, then as many more images as there are cores to fill
     want = [i for i in PARITY_IMAGES if i < batch]
     images = (want + [i for i in range(batch) if i not in want])[:max(n_procs, 1) + 1]   # 1 alone, then n_procs at once
