@@ -563,6 +563,18 @@ def test_c_driver_over_files_matches_reference_flow(pkg, device, weights, tmp_pa
     assert r2.returncode == 0, r2.stdout[-400:] + r2.stderr[-400:]
     assert (tmp_path / "Data" / "fp16x2_result.txt").read_text().splitlines()[0].split("/")[0] == \
         (tmp_path / "Data" / "opencl_result.txt").read_text().splitlines()[0].split("/")[0]
+    # the offline repack from C: the first run with a planes file writes it, the second starts from it alone (the
+    # Network directory is gone by then) and prints the same result lines
+    r3 = subprocess.run([str(exe), "./Data/input-100.bin", "./Network", "./Data/planes_result_1.txt", "./b16.planes"], cwd=tmp_path,
+                        capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0 and (tmp_path / "b16.planes").stat().st_size > 800e6, r3.stdout[-400:] + r3.stderr[-400:]
+    shutil.move(str(tmp_path / "Network"), str(tmp_path / "Network_gone"))
+    r4 = subprocess.run([str(exe), "./Data/input-100.bin", "./Network", "./Data/planes_result_2.txt", "./b16.planes"], cwd=tmp_path,
+                        capture_output=True, text=True, timeout=300)
+    assert r4.returncode == 0 and "no weight files read" in r4.stdout, r4.stdout[-400:] + r4.stderr[-400:]
+    first = (tmp_path / "Data" / "opencl_result.txt").read_text()
+    assert (tmp_path / "Data" / "planes_result_1.txt").read_text() == first == (tmp_path / "Data" / "planes_result_2.txt").read_text()
+    (tmp_path / "b16.planes").unlink()
     gold = np.load(root / "tests" / "golden" / "b16_full_rounded.npz")
     lines = (tmp_path / "Data" / "opencl_result.txt").read_text().splitlines()
     assert len(lines) == 4
