@@ -167,3 +167,25 @@ def test_vit_l16_bf16_at_256_images_is_batch_position_independent(pkg, device, l
     ls, ps = small.forward(imgs[pick])
     small.close()
     assert np.isfinite(lb).all() and np.array_equal(lb[pick], ls) and np.array_equal(pb[pick], ps)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_repacked_weights_file_round_trip_for_the_vit_h14_shapes(pkg, device, h14, tmp_path, precision):
+    """vit_hip_export_planes / vit_hip_create_from_planes on ViT-H/14's shapes (two layers of it: E = 1280, F = 5120, patch 14 --
+    the conv_proj planes are padded from K = 588 to 640 -- and the MX / one-part slabs of config 5's and config 4's
+    precisions): the context rebuilt from the one file gives bit-identical logits, and reports the shape it was written with."""
+    cfg, weights = h14
+    short = pkg.preset("vit_h_14")
+    short.depth = 2
+    w2 = weights[:4 + 12 * 2] + weights[-4:]
+    imgs = pkg.synth_images(cfg, 11, 2)
+    a = pkg.ViTHip(short, w2, device=0, max_batch=2, precision=precision)
+    la, pa = a.forward(imgs)
+    path = tmp_path / f"h14_two_layers_{precision}.planes"
+    a.export_planes(path)
+    a.close()
+    b = pkg.ViTHip.from_planes(path, device=0, max_batch=2)
+    assert (b.precision, b.cfg.depth, b.cfg.embed_dim, b.cfg.patch_size, b.cfg.num_heads) == (precision, 2, 1280, 14, 16)
+    lb, pb = b.forward(imgs)
+    b.close()
+    assert np.isfinite(la).all() and np.array_equal(la, lb) and np.array_equal(pa, pb)
