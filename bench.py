@@ -204,6 +204,7 @@ def in_library_multi_child(n_dev: int, first_dev: int, B: int, steps: int) -> No
     for _ in range(steps):
         m.forward_device(ptrs, counts, d_logits.ptr, d_probs.ptr)     # synchronous on return
     dt = (time.perf_counter() - t0) / steps
+    enqueue_ms = m.last_enqueue_ms()          # per device: host time its thread took to enqueue its shard (last step)
     pkg.binding.check(L.vh_set_device(devices[0]), "vh_set_device")
     got = d_logits.to_numpy((n_dev, B, NC))
     probs = d_probs.to_numpy((n_dev * B, NC))
@@ -224,13 +225,18 @@ def in_library_multi_child(n_dev: int, first_dev: int, B: int, steps: int) -> No
         verified += 1
     one.close()
     m.close()
-    print(json.dumps({"what": "vit_hip_create_multi + vit_hip_forward_device_multi: one process, one replica and one stream per "
-                              "device, image shards resident in HBM, logits gathered on the first device by grouped "
-                              "ncclSend/ncclRecv in C (librccl opened at run time), softmax of all rows on the root; "
-                              "synchronous per step", "devices": devices, "batch_per_device": B, "steps": steps,
+    print(json.dumps({"what": "vit_hip_create_multi + vit_hip_forward_device_multi: one process, one replica, one stream and one "
+                              "enqueuing host thread per device, image shards resident in HBM, logits gathered on the first "
+                              "device by grouped ncclSend/ncclRecv in C (librccl opened at run time), softmax of all rows on "
+                              "the root; synchronous per step", "devices": devices, "batch_per_device": B, "steps": steps,
                       "value": round(n_dev * B / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3),
-                      "gathered_shards_verified_bitwise": verified, "logits_finite": bool(np.isfinite(got).all()),
+                      "host_enqueue_ms": enqueue_ms,
+                      "gathered_shards_verified_bitwise": verified,
+                      "gather_verified": (verified == n_dev - 1) if n_dev > 1 else None,   # None: one device, nothing was exchanged
+                      "logits_finite": bool(np.isfinite(got).all()),
                       "prob_sum_last_image": float(probs[-1].sum())}), flush=True)
+    if n_dev > 1 and verified != n_dev - 1:
+        raise SystemExit(f"in-library multi-GPU leg: {verified} of {n_dev - 1} gathered shards verified")
 
 
 def run_in_library_multi(n_dev: int, first_dev: int, B: int) -> dict:
@@ -267,6 +273,8 @@ def main() -> None:
                     help="vit_b_16 is BASELINE.json's metric; the others are the parity-test shapes, timed for DESIGN.md")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (0 = auto)")
     ap.add_argument("--no-in-library-multi", action="store_true", help="skip the in-library multi-GPU leg (child process)")
+    ap.add_argument("--sustain-s", type=float, default=30.0,
+                    help="seconds of the same step behind the timed region for the `sustained` leg (0 = skip)")
     ap.add_argument("--in-library-multi-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--first-device", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -377,6 +385,53 @@ def main() -> None:
 
     if comm is not None:
         elapsed = comm.max_over_ranks(elapsed)
+
+    # Sustained load: the SAME step for >= 30 s of wall time behind the timed region.  `value` rests on a window of a
+    # second or two on a board that regulates power over milliseconds and temperature over tens of seconds; this leg
+    # says what the rate is once the board is warm.  Every rank runs the same number of steps (the count follows from
+    # the max-over-ranks time above), synchronised about once a second; fc1's per-launch time (HIP events, as in the
+    # timed region) is the clock proxy.  No reference counterpart (Main.c:51-57 times one shot).
+    sustained = None
+    if args.sustain_s > 0:
+        step_s = elapsed / args.steps
+        chunk = max(1, int(round(1.0 / step_s)))
+        n_chunks = max(2, int(np.ceil(args.sustain_s / (chunk * step_s))))
+        model.profile_select(["fc1_gemm"])
+        model.profile_enable(chunk)          # every read below rewinds the event pool
+        marks, fc1_marks = [], []
+        fence()
+        t0s = time.perf_counter()
+        for _ in range(n_chunks):
+            for _ in range(chunk):
+                step()
+            if use_rccl:
+                torch.cuda.synchronize()
+            pkg.binding.check(L.vh_device_sync(), "sync")
+            marks.append(time.perf_counter() - t0s)
+            ms_c, cnt_c = model.profile_read()["fc1_gemm"]
+            fc1_marks.append(ms_c / max(cnt_c, 1))
+        model.profile_enable(0)
+        model.profile_select(None)
+        total_s = marks[-1]
+
+        def window(lo_s, hi_s):
+            """chunks that END inside (lo_s, hi_s]: images/s per GPU and mean fc1 ms over them"""
+            idx = [k for k, t in enumerate(marks) if lo_s < t <= hi_s] or [len(marks) - 1]
+            t_begin = marks[idx[0] - 1] if idx[0] > 0 else 0.0
+            rate = len(idx) * chunk * B / (marks[idx[-1]] - t_begin)
+            return rate, float(np.mean([fc1_marks[k] for k in idx]))
+        first_rate, first_fc1 = window(0.0, 5.0)
+        last_rate, last_fc1 = window(total_s - 5.0, total_s)
+        if comm is not None:     # slowest rank decides, as for `value`
+            first_rate = B * chunk / comm.max_over_ranks(B * chunk / first_rate)
+            last_rate = B * chunk / comm.max_over_ranks(B * chunk / last_rate)
+        sustained = {"what": f"the same step repeated for {total_s:.1f} s behind the timed region ({chunk * n_chunks} steps, host "
+                             f"sync every {chunk}); whole-job images/sec over the first and the last 5 s, fc1 ms per launch "
+                             "(HIP events) as the clock proxy",
+                     "seconds": round(total_s, 2), "steps": chunk * n_chunks,
+                     "first_5s": {"value": round(world * first_rate, 1), "fc1_ms": round(first_fc1, 4)},
+                     "last_5s": {"value": round(world * last_rate, 1), "fc1_ms": round(last_fc1, 4)},
+                     "mean": round(world * B * chunk * n_chunks / total_s, 1), "unit": "images/sec"}
 
     # N > 1: rank 0 checks what the gather delivered.  Its own rows must be its own logits; for every other rank
     # it recomputes that rank's first and last images (global index r*B + i) ON THE SAME BATCH POSITIONS -- so the
@@ -656,6 +711,10 @@ def main() -> None:
             "kernels_note": f"per-operator averages from a separate pass of {PROF_STEPS} steps with every launch bracketed "
                             "by HIP events; the roofline kernel is bracketed inside the timed region",
         }
+        if sustained is not None:
+            sustained["last_5s_vs_value"] = round(sustained["last_5s"]["value"] / value, 4)
+            sustained["last_5s_more_than_3pct_below_value"] = bool(sustained["last_5s"]["value"] < 0.97 * value)
+            out["sustained"] = sustained
         if bf16_leg is not None:
             out["bf16_gemm_mode"] = bf16_leg
             out["fp8_block_scaled_gemm_mode"] = fp8_leg

@@ -143,16 +143,23 @@ int vit_hip_device(const vit_hip_ctx *ctx);   /* the device a context lives on *
 /* Device-resident form with the classifier gather over RCCL (the one exchange of the path; grouped ncclSend / ncclRecv
  * between the devices' compute streams, device 0 of `m` is the root): d_images[g] = shard g's images, [counts[g]][C][H][W]
  * fp32 resident on device g of `m` (counts[g] <= max_batch_per_device); d_logits_root and d_probs_root (may be NULL) =
- * [sum counts][classes] fp32 on device 0, shard after shard.  Synchronous on return.  librccl is opened at run time on
- * first use (an RCCL already in the process, e.g. PyTorch's, is taken); devices must be distinct. */
+ * [sum counts][classes] fp32 on device 0, shard after shard.  Synchronous on return -- on success AND on failure (every
+ * device's stream is waited for before an error is returned, so the caller may free its buffers).  The shards are
+ * enqueued concurrently, one host thread per device.  librccl is opened at run time on first use (an RCCL already in
+ * the process, e.g. PyTorch's, is taken); devices must be distinct. */
 int vit_hip_forward_device_multi(vit_hip_multi *m, const float *const *d_images, const int *counts, float *d_logits_root,
                                  float *d_probs_root);
+/* Host milliseconds each device's thread spent enqueuing its shard in the last vit_hip_forward_device_multi (ms[d] for
+ * device d of `m`); returns the device count, -1 if `capacity` is too small. */
+int vit_hip_multi_last_enqueue_ms(const vit_hip_multi *m, double *ms, int capacity);
 /* The sharding primitives on their own (host logic, no device needed): shard `shard` of [0, total) cut
  * into n_shards contiguous pieces of ceil(total / n_shards); and a runner that calls
  * fn(arg, shard, lo, hi) for every non-empty shard, each on its own host thread, and returns 0 or the
  * first failing shard's status. */
 void vit_shard_range(int total, int shard, int n_shards, int *lo, int *hi);
 int vit_shard_run(int total, int n_shards, int (*fn)(void *arg, int shard, int lo, int hi), void *arg);
+/* ... also reporting the wall time of every shard's fn on its thread (ms_per_shard[n_shards]; may be NULL) */
+int vit_shard_run_timed(int total, int n_shards, int (*fn)(void *arg, int shard, int lo, int hi), void *arg, double *ms_per_shard);
 
 /* Introspection for tests / profiling. */
 const vit_config *vit_hip_config(const vit_hip_ctx *ctx);

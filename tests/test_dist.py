@@ -46,7 +46,7 @@ def test_bench_two_ranks_launch_themselves_verify_the_gather_and_report_the_cpu_
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(VIT_DIST_BACKEND="gloo", VIT_BENCH_DEVICE="0")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", "64", "--cpu-procs", "2"], env=env, capture_output=True, text=True, timeout=900)
+                        "--batch", "64", "--cpu-procs", "2", "--sustain-s", "3"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -59,6 +59,10 @@ def test_bench_two_ranks_launch_themselves_verify_the_gather_and_report_the_cpu_
     assert out["checks"]["logits_finite"]
     lib_leg = out["in_library_multi_gpu"]          # the C-side RCCL entry, degenerate group of one on this box
     assert "error" not in lib_leg and lib_leg["devices"] == [0] and lib_leg["value"] > 0 and lib_leg["logits_finite"]
+    assert len(lib_leg["host_enqueue_ms"]) == 1 and 0.0 < lib_leg["host_enqueue_ms"][0] < 1000.0 and lib_leg["gather_verified"] is None
+    sus = out["sustained"]                          # the same step for a few seconds behind the timed region, both ranks in step
+    assert sus["seconds"] >= 2.5 and sus["first_5s"]["value"] > 0 and sus["last_5s"]["value"] > 0 and sus["last_5s"]["fc1_ms"] > 0
+    assert isinstance(sus["last_5s_more_than_3pct_below_value"], bool)
 
 
 @pytest.mark.gpu
@@ -70,7 +74,7 @@ def test_bench_rccl_branch_with_a_group_of_one():
     env = {k: v for k, v in os.environ.items() if k not in ("VIT_DIST_BACKEND", "VIT_BENCH_DEVICE")}
     env.update(VIT_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64",
-                        "--no-cpu-baseline", "--no-in-library-multi"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-in-library-multi", "--sustain-s", "2"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["gather"]["backend"] == "rccl" and out["gather"]["rccl_ranks"] == 1

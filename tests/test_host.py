@@ -221,6 +221,50 @@ def test_shard_runner_covers_the_batch_once_and_reports_failures(pkg):
     assert L.vit_shard_run(100, 0, fail, None) != 0 and L.vit_shard_run(-1, 2, fail, None) != 0
 
 
+def test_shards_are_entered_concurrently_and_timed(pkg):
+    """The enqueue stage of vit_hip_forward_device_multi (csrc/vit_gather_rccl.c) is vit_shard_run_timed with one shard
+    per device.  A stub "enqueue" that waits at a rendezvous for ALL shards can only return if every shard was entered
+    before any had finished -- a runner that entered them one after the other (round 3's loop) times out at the barrier.
+    The per-shard host times come back, and a failing shard's status wins after every other shard has been joined."""
+    import threading
+    import time
+    L, b = pkg.lib(), pkg.binding
+    for n in (2, 4, 8):
+        barrier = threading.Barrier(n, timeout=20.0)
+        inside, lock, peak = [0], threading.Lock(), [0]
+
+        def stub(arg, shard, lo, hi):
+            assert hi - lo == 1 and lo == shard
+            with lock:
+                inside[0] += 1
+                peak[0] = max(peak[0], inside[0])
+            try:
+                barrier.wait()
+            except threading.BrokenBarrierError:
+                return 9
+            time.sleep(0.002 * (shard + 1))
+            with lock:
+                inside[0] -= 1
+            return 0
+        ms = (C.c_double * n)()
+        assert L.vit_shard_run_timed(n, n, b.SHARD_FN(stub), None, ms) == 0
+        assert peak[0] == n                                   # all shards were inside the stub at once
+        assert all(ms[s_] >= 2.0 * (s_ + 1) * 0.9 for s_ in range(n)) and max(ms) < 20000.0
+    # a failing shard: its status is returned, and only after the slow shards have finished (nothing left running)
+    done = []
+
+    def slow_or_fail(arg, shard, lo, hi):
+        if shard == 1:
+            return 5
+        time.sleep(0.05)
+        done.append(shard)
+        return 0
+    ms = (C.c_double * 4)()
+    assert L.vit_shard_run_timed(4, 4, b.SHARD_FN(slow_or_fail), None, ms) == 5
+    assert sorted(done) == [0, 2, 3]
+    assert L.vit_shard_run_timed(4, 4, b.SHARD_FN(slow_or_fail), None, None) == 5      # the times are optional
+
+
 def test_fp8_reference_round_trips_every_code():
     """tests/fp8_ref.py (the numpy statement of OCP e4m3 the GPU casts are checked against):
     every finite code survives dequantise -> quantise, ties go to the even code, overflow

@@ -28,6 +28,17 @@ void launch_variant(hipStream_t st, MxParams p)
     p.ntiles = p.N / BN;
     hipLaunchKernelGGL((gemm_mx_kernel<NW, BN, EPI, OUTK, LAB>), dim3(p.mtiles * p.ntiles), dim3(64 * NW), LDS, st, p);
 }
+
+/* round 4: the two co-resident workgroups of a CU half a tile apart (gemm_common.h lab_stagger_start) */
+unsigned *g_slots;
+template <int EPI, int OUTK, int CYCLES, bool BY_SLOT>
+void launch_stagger(hipStream_t st, MxParams p)
+{
+    p.lab_lo = 256; p.lab_hi = 512; p.lab_cycles = CYCLES; p.lab_slots = g_slots;
+    if (BY_SLOT)
+        CK(hipMemsetAsync(g_slots, 0, 4096 * sizeof(unsigned), st));
+    launch_variant<4, 256, EPI, OUTK, BY_SLOT ? 1024 : 512>(st, p);
+}
 }
 
 int main(int argc, char **argv)
@@ -68,6 +79,17 @@ int main(int argc, char **argv)
         {"no GELU, MX out                      ", launch_variant<4, 256, EPI_NONE, OUT_MX, 0>},
         {"no GELU, fp32, no stores/movement    ", launch_variant<4, 256, EPI_NONE, OUT_F32, 64 + 7>},
     };
+#define STAG(E, O, C) {"[256,512) late by " #C "             ", launch_stagger<E, O, C, false>}, {"2nd on CU late by " #C "             ", launch_stagger<E, O, C, true>}
+    CK(hipMalloc(&g_slots, 4096 * sizeof(unsigned)));
+    if (argc >= 5 && argv[4][0] == 's')   /* "stagger" */
+        vs = {
+            {"product: 128x256 (fc1: GELU, MX out) ", launch_variant<4, 256, EPI_GELU, OUT_MX, 0>},
+            STAG(EPI_GELU, OUT_MX, 2000), STAG(EPI_GELU, OUT_MX, 4000), STAG(EPI_GELU, OUT_MX, 6000), STAG(EPI_GELU, OUT_MX, 9000),
+            STAG(EPI_GELU, OUT_MX, 12000),
+            {"no GELU, fp16 planes out (QKV epi.)  ", launch_variant<4, 256, EPI_NONE, OUT_PLANES_H, 0>},
+            STAG(EPI_NONE, OUT_PLANES_H, 3000), STAG(EPI_NONE, OUT_PLANES_H, 6000),
+        };
+    else
     if (resid) {
         p.R = xres; p.C = xres; p.Cs = nullptr;
         vs = {

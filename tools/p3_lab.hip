@@ -213,6 +213,19 @@ void launch_variant(hipStream_t st, P3Params p)
     p.ntiles = p.N / BN;
     hipLaunchKernelGGL((gemm_p3_kernel<NW, BN, EPI, OUTK, NPL, LAB>), dim3(p.mtiles * p.ntiles), dim3(64 * NW), LDS, st, p);
 }
+
+/* round 4: the two co-resident 128x256 workgroups of a CU half a tile apart (gemm_common.h lab_stagger_start).
+ * BY_SLOT: the second workgroup to ARRIVE on a CU is the late one (counters zeroed before every launch); otherwise the
+ * workgroups [256, 512) of the grid are. */
+unsigned *g_slots;
+template <int EPI, int OUTK, int CYCLES, bool BY_SLOT>
+void launch_stagger(hipStream_t st, P3Params p)
+{
+    p.lab_lo = 256; p.lab_hi = 512; p.lab_cycles = CYCLES; p.lab_slots = g_slots;
+    if (BY_SLOT)
+        CK(hipMemsetAsync(g_slots, 0, 4096 * sizeof(unsigned), st));
+    launch_variant<4, 256, EPI, OUTK, BY_SLOT ? 1024 : 512, 1>(st, p);
+}
 }
 
 int main(int argc, char **argv)
@@ -303,6 +316,25 @@ int main(int argc, char **argv)
             {"no stores, no reads/DMA/A loads  ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64 + 7, 1>},
             {"no stores/reads/DMA/A/barrier    ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 64 + 15, 1>},
         };
+#define STAG(E, O, C) {"128x256, [256,512) late by " #C, launch_stagger<E, O, C, false>}, {"128x256, 2nd on CU late by " #C, launch_stagger<E, O, C, true>}
+    if (argc >= 6 && parts == 1 && argv[5][0] == 's') {   /* "stagger": fc1 (GELU, planes out) */
+        CK(hipMalloc(&g_slots, 4096 * sizeof(unsigned)));
+        vs = {
+            {"256x256, one workgroup per CU    ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"128x256, two per CU, in step     ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            STAG(EPI_GELU, OUT_PLANES, 3000), STAG(EPI_GELU, OUT_PLANES, 6000), STAG(EPI_GELU, OUT_PLANES, 9000),
+            STAG(EPI_GELU, OUT_PLANES, 12000), STAG(EPI_GELU, OUT_PLANES, 16000), STAG(EPI_GELU, OUT_PLANES, 22000),
+            {"128x256, no stores, in step      ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 64, 1>},
+        };
+    } else if (argc >= 6 && parts == 1 && argv[5][0] == 'q') {   /* "qkv-stagger": no GELU, fp16 planes out */
+        CK(hipMalloc(&g_slots, 4096 * sizeof(unsigned)));
+        vs = {
+            {"256x256, one workgroup per CU    ", launch_variant<8, 256, EPI_NONE, OUT_PLANES_H, 0, 1>},
+            {"128x256, two per CU, in step     ", launch_variant<4, 256, EPI_NONE, OUT_PLANES_H, 0, 1>},
+            STAG(EPI_NONE, OUT_PLANES_H, 3000), STAG(EPI_NONE, OUT_PLANES_H, 6000), STAG(EPI_NONE, OUT_PLANES_H, 9000),
+            STAG(EPI_NONE, OUT_PLANES_H, 12000), STAG(EPI_NONE, OUT_PLANES_H, 16000),
+        };
+    } else
     if (argc >= 6 && parts == 1) {   /* "resid": the residual epilogue (out-projection / fc2 shapes), fp32 rows in place */
         float *xres;
         CK(hipMalloc(&xres, (size_t)M * N * 4));

@@ -998,13 +998,16 @@ struct shard_job
     int (*fn)(void *arg, int shard, int lo, int hi);
     void *arg;
     int shard, lo, hi, rc;
+    double ms;          /* wall time of fn on its thread */
     char err[256];
 };
 
 static void *shard_worker(void *p)
 {
     struct shard_job *j = (struct shard_job *)p;
+    const double t0 = wall_seconds();
     j->rc = j->fn(j->arg, j->shard, j->lo, j->hi);
+    j->ms = 1e3 * (wall_seconds() - t0);
     if (j->rc != 0)
         snprintf(j->err, sizeof(j->err), "%s", vh_last_error());   /* the error text is per thread */
     return NULL;
@@ -1014,6 +1017,12 @@ static void *shard_worker(void *p)
  * on its own host thread (shard 0 on the caller's); returns 0 or the first failing shard's status. */
 int vit_shard_run(int total, int n_shards, int (*fn)(void *arg, int shard, int lo, int hi), void *arg)
 {
+    return vit_shard_run_timed(total, n_shards, fn, arg, NULL);
+}
+
+/* The same; ms_per_shard[s] (may be NULL) receives the wall time shard s's fn took on its thread (0 for an empty shard). */
+int vit_shard_run_timed(int total, int n_shards, int (*fn)(void *arg, int shard, int lo, int hi), void *arg, double *ms_per_shard)
+{
     enum { MAX_SHARDS = 64 };
     if (total < 0 || n_shards <= 0 || n_shards > MAX_SHARDS || !fn)
         return 1;
@@ -1021,7 +1030,7 @@ int vit_shard_run(int total, int n_shards, int (*fn)(void *arg, int shard, int l
     pthread_t tid[MAX_SHARDS];
     int threaded[MAX_SHARDS];
     for (int s = 0; s < n_shards; ++s) {
-        jobs[s] = (struct shard_job){fn, arg, s, 0, 0, 0, ""};
+        jobs[s] = (struct shard_job){fn, arg, s, 0, 0, 0, 0.0, ""};
         vit_shard_range(total, s, n_shards, &jobs[s].lo, &jobs[s].hi);
         threaded[s] = 0;
     }
@@ -1034,6 +1043,9 @@ int vit_shard_run(int total, int n_shards, int (*fn)(void *arg, int shard, int l
     for (int s = 1; s < n_shards; ++s)
         if (threaded[s])
             pthread_join(tid[s], NULL);
+    if (ms_per_shard)
+        for (int s = 0; s < n_shards; ++s)
+            ms_per_shard[s] = jobs[s].ms;
     for (int s = 0; s < n_shards; ++s)
         if (jobs[s].rc != 0) {
             fprintf(stderr, "vit_shard_run: shard %d [%d, %d) failed with status %d: %s\n", s, jobs[s].lo, jobs[s].hi,
@@ -1057,10 +1069,21 @@ struct vit_hip_multi
     float *logits;
     float **probs;
     void *gather;   /* RCCL communicators of vit_hip_forward_device_multi (vit_gather_rccl.c), made on first use */
+    double enqueue_ms[64];   /* vit_hip_forward_device_multi: host time each device's thread spent enqueuing its shard, last call */
 };
 
 void vit_gather_release(void *state);
 void **vit_hip_multi_gather_slot(vit_hip_multi *m) { return &m->gather; }
+double *vit_hip_multi_enqueue_ms_slot(vit_hip_multi *m) { return m->enqueue_ms; }
+
+int vit_hip_multi_last_enqueue_ms(const vit_hip_multi *m, double *ms, int capacity)
+{
+    if (!m || !ms || capacity < m->n_devices)
+        return -1;
+    for (int d = 0; d < m->n_devices; ++d)
+        ms[d] = m->enqueue_ms[d];
+    return m->n_devices;
+}
 
 static int multi_create_one(void *arg, int shard, int lo, int hi)
 {

@@ -53,6 +53,8 @@ struct MxParams {
     const float *bias, *R;
     void *C, *Cs;             /* fp32 [a_rows][N]; or MX values [N/128][a_rows][128] + scales [N/128][4][a_rows] */
     int row_begin, row_end, N, K, a_rows, mtiles, ntiles;
+    int lab_lo, lab_hi, lab_cycles;   /* LAB bits 512 / 1024 only (lab_stagger_start) */
+    unsigned *lab_slots;
 };
 
 /* LAB (tools/mx_lab.hip only; 0 in the library): bit 1 skips the W DMA after the prologue, bit 2 the A loads after the
@@ -70,6 +72,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    if (LAB & (512 | 1024))
+        lab_stagger_start(p.lab_lo, p.lab_hi, p.lab_cycles, (LAB & 1024) ? p.lab_slots : nullptr);
     const int tile = xcd_tile(blockIdx.x, p.mtiles * p.ntiles);
     const int m0 = p.row_begin + (tile / p.ntiles) * BM;
     const int n0 = (tile % p.ntiles) * BN;

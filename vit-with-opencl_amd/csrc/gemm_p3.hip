@@ -74,6 +74,8 @@ struct P3Params {
      * plus that token's position embedding (ViT_seq.c:65-80,114-117) */
     const float *pos;         /* [tokens][N] */
     int np, tokens;
+    int lab_lo, lab_hi, lab_cycles;   /* LAB bits 512 / 1024 only (lab_stagger_start) */
+    unsigned *lab_slots;
 };
 
 /* NPL = parts per value: 3 = the exact fp32 split (six products per block, the default fp32 path);
@@ -103,6 +105,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    if (LAB & (512 | 1024))
+        lab_stagger_start(p.lab_lo, p.lab_hi, p.lab_cycles, (LAB & 1024) ? p.lab_slots : nullptr);
     const int tile = xcd_tile(blockIdx.x, p.mtiles * p.ntiles);
     const int m0 = p.row_begin + (tile / p.ntiles) * BM;
     const int n0 = (tile % p.ntiles) * BN;

@@ -41,6 +41,7 @@ struct vit_gather_state
 void **vit_hip_multi_gather_slot(vit_hip_multi *m);
 float *vit_hip_logits_buffer(vit_hip_ctx *ctx);
 int vit_hip_device(const vit_hip_ctx *ctx);
+double *vit_hip_multi_enqueue_ms_slot(vit_hip_multi *m);
 
 static int fail(int code, const char *what, const char *detail)
 {
@@ -129,8 +130,51 @@ static int gather_state(vit_hip_multi *m, struct vit_gather_state **out)
     return 0;
 }
 
+/* One device's share of the enqueue stage: its shard's ~7 launches per layer, asynchronous on its own stream. */
+struct enqueue_job
+{
+    vit_hip_multi *m;
+    const float *const *d_images;
+    const int *counts;
+    float *d_logits_root;
+};
+
+static int enqueue_shard(void *arg, int g, int lo, int hi)
+{
+    const struct enqueue_job *j = (const struct enqueue_job *)arg;
+    (void)lo;
+    (void)hi;
+    if (j->counts[g] == 0)
+        return 0;
+    vit_hip_ctx *ctx = vit_hip_multi_ctx(j->m, g);
+    /* shard 0 writes straight into the gathered buffer */
+    return vit_hip_forward_device(ctx, j->d_images[g], j->counts[g], g == 0 ? j->d_logits_root : vit_hip_logits_buffer(ctx), NULL,
+                                  vit_hip_stream(ctx));
+}
+
+/* Wait for everything this call may have put on any device's stream.  Every return path behind the first enqueue goes
+ * through here: the entry is synchronous on failure too, so the caller may free d_logits_root and the images. */
+static int sync_all(vit_hip_multi *m, int rc)
+{
+    for (int g = vit_hip_multi_devices(m) - 1; g >= 0; --g) {   /* the root (device 0) last: its stream holds the receives */
+        vit_hip_ctx *ctx = vit_hip_multi_ctx(m, g);
+        int src = vh_set_device(vit_hip_device(ctx));
+        if (src == 0)
+            src = vh_stream_sync(vit_hip_stream(ctx));
+        if (rc == 0)
+            rc = src;
+    }
+    return rc;
+}
+
 /* d_images[g]: shard g's images ([counts[g]][C][H][W] fp32) resident on device g of `m`; d_logits_root / d_probs_root:
- * [sum counts][classes] fp32 on device 0 of `m`, shard after shard (probs may be NULL).  Synchronous on return. */
+ * [sum counts][classes] fp32 on device 0 of `m`, shard after shard (probs may be NULL).  Synchronous on return, on
+ * success and on failure alike.
+ *
+ * The shards are enqueued CONCURRENTLY, one host thread per device (vit_shard_run_timed, as vit_hip_forward_multi
+ * does): a forward is ~90 launches, ~0.4 ms of host time, and from one thread device 7 would start ~3 ms late -- nothing
+ * at 86 ms per step, a sixth of the fp8 mode's step.  The per-shard host enqueue times of the last call are kept for
+ * vit_hip_multi_last_enqueue_ms. */
 int vit_hip_forward_device_multi(vit_hip_multi *m, const float *const *d_images, const int *counts, float *d_logits_root,
                                  float *d_probs_root)
 {
@@ -151,19 +195,16 @@ int vit_hip_forward_device_multi(vit_hip_multi *m, const float *const *d_images,
         return rc;
     const size_t NC = (size_t)vit_hip_config(vit_hip_multi_ctx(m, 0))->num_classes;
 
-    /* every shard's forward, asynchronous on its device's stream; shard 0 writes straight into the gathered buffer */
-    for (int g = 0; g < n; ++g) {
-        vit_hip_ctx *ctx = vit_hip_multi_ctx(m, g);
-        if (counts[g] == 0)
-            continue;
-        rc = vit_hip_forward_device(ctx, d_images[g], counts[g], g == 0 ? d_logits_root : vit_hip_logits_buffer(ctx), NULL,
-                                    vit_hip_stream(ctx));
-        if (rc)
-            return rc;
-    }
+    /* every shard's forward, asynchronous on its device's stream, entered from its own host thread */
+    struct enqueue_job job = {m, d_images, counts, d_logits_root};
+    rc = vit_shard_run_timed(n, n, enqueue_shard, &job, vit_hip_multi_enqueue_ms_slot(m));
+    if (rc)
+        return sync_all(m, rc);   /* the other shards' kernels still write their logits buffers: wait them out */
+
     /* the gather: grouped point-to-point on the compute streams, so it is ordered behind each shard's kernels */
     if (n > 1) {
         int nrc = gs->GroupStart();
+        const int opened = nrc == 0;
         size_t offset = (size_t)counts[0] * NC;
         for (int g = 1; g < n && nrc == 0; ++g) {
             if (counts[g] == 0)
@@ -175,22 +216,18 @@ int vit_hip_forward_device_multi(vit_hip_multi *m, const float *const *d_images,
                 nrc = gs->Send(vit_hip_logits_buffer(ctx), (size_t)counts[g] * NC, RCCL_FLOAT32, 0, gs->comms[g], vit_hip_stream(ctx));
             offset += (size_t)counts[g] * NC;
         }
-        const int erc = gs->GroupEnd();
-        if (nrc == 0)
-            nrc = erc;
+        if (opened) {   /* a group that was opened is always closed, whatever happened inside it */
+            const int erc = gs->GroupEnd();
+            if (nrc == 0)
+                nrc = erc;
+        }
         if (nrc != 0)
-            return fail(114, "RCCL gather failed", gs->GetErrorString(nrc));
+            return sync_all(m, fail(114, "RCCL gather failed", gs->GetErrorString(nrc)));
     }
     /* class softmax of all rows on the root (miniSoftMax.cl; ViT_seq.c:372-397), behind the receives on its stream */
     vit_hip_ctx *root = vit_hip_multi_ctx(m, 0);
-    if ((rc = vh_set_device(vit_hip_device(root))) != 0)
-        return rc;
-    if (d_probs_root && (rc = vh_launch_softmax(vit_hip_stream(root), d_logits_root, d_probs_root, total, (int)NC)) != 0)
-        return rc;
-    for (int g = n - 1; g >= 0; --g) {   /* synchronous on return; the root last */
-        vit_hip_ctx *ctx = vit_hip_multi_ctx(m, g);
-        if ((rc = vh_set_device(vit_hip_device(ctx))) != 0 || (rc = vh_stream_sync(vit_hip_stream(ctx))) != 0)
-            return rc;
-    }
-    return 0;
+    rc = vh_set_device(vit_hip_device(root));
+    if (rc == 0 && d_probs_root)
+        rc = vh_launch_softmax(vit_hip_stream(root), d_logits_root, d_probs_root, total, (int)NC);
+    return sync_all(m, rc);
 }

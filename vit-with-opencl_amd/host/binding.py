@@ -47,7 +47,8 @@ EXPORTS = [
     "vh_launch_attention_planes_f16_hd80", "vh_launch_attention_planes_f16_hd80_operand",
     "vh_launch_gather_rows", "vit_hip_set_last_layer_cls_only",
     "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
-    "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run", "vit_hip_forward_device_multi", "vit_hip_device", "vh_set_error",
+    "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run", "vit_shard_run_timed", "vit_hip_multi_last_enqueue_ms",
+    "vit_hip_forward_device_multi", "vit_hip_device", "vh_set_error",
     "vit_synth_fill", "vit_synth_tensor", "vit_synth_image",
     "load_image_data", "load_weights", "vit_write_image_file", "vit_write_weight_file",
     "vit_write_result_file", "vit_compare_rows",
@@ -215,6 +216,8 @@ def lib() -> C.CDLL:
     L.vit_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     L.vit_shard_range.restype = None
     L.vit_shard_run.argtypes = [i, i, SHARD_FN, voidp]
+    L.vit_shard_run_timed.argtypes = [i, i, SHARD_FN, voidp, C.POINTER(C.c_double)]
+    L.vit_hip_multi_last_enqueue_ms.argtypes = [voidp, C.POINTER(C.c_double), i]
     L.vit_hip_forward.argtypes = [voidp, C.POINTER(ImageData), i, f32p, C.POINTER(f32p)]
     L.vit_hip_forward_device.argtypes = [voidp, voidp, i, voidp, voidp, voidp]
     L.vit_hip_stream.argtypes = [voidp]
@@ -459,6 +462,12 @@ class ViTHipMulti:
         ptrs = (voidp * n)(*[p if isinstance(p, voidp) else voidp(p) for p in d_images])
         check(self.L.vit_hip_forward_device_multi(self.handle, ptrs, (C.c_int * n)(*counts), d_logits_root, d_probs_root),
               "vit_hip_forward_device_multi")
+
+    def last_enqueue_ms(self) -> list[float]:
+        """Host milliseconds each device's thread spent enqueuing its shard in the last forward_device."""
+        ms = (C.c_double * 64)()
+        n = self.L.vit_hip_multi_last_enqueue_ms(self.handle, ms, 64)
+        return [round(ms[d], 4) for d in range(max(n, 0))]
 
     def close(self):
         if self.handle:
