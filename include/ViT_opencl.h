@@ -86,6 +86,10 @@ enum { VIT_PRECISION_F32 = 0, VIT_PRECISION_BF16_GEMM = 1, VIT_PRECISION_FP8_GEM
 int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *networks,
                       int n_tensors, int device, int max_batch, int precision);
 int vit_hip_precision(const vit_hip_ctx *ctx);
+/* 1 when the context folds every LayerNorm but the final one into the projection behind it (csrc/norm_fold.h): the
+ * default of BF16_GEMM and FP8_GEMM ($VIT_HIP_LN_FOLD=0 at creation keeps the separate LayerNorm launches); never for
+ * the fp32 paths. */
+int vit_hip_ln_fold(const vit_hip_ctx *ctx);
 
 /* Repacked weights on disk (the offline half of the weight-format tooling): export writes what the context holds in HBM
  * after its repack -- every tensor in fp32 (reference order) plus the precision's GEMM-operand copy of the four big

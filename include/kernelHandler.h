@@ -108,6 +108,15 @@ int vh_launch_patch_embed_ws(vh_stream_t s, const float *images, const float *co
  * embedding and class-token rows as vh_launch_patch_embed; pixels and weights are rounded to bf16.  embed % 128 == 0. */
 int vh_patch_planes_k(int in_chans, int patch_size);
 int vh_launch_conv_weight_planes(vh_stream_t s, const float *conv_w, void *planes, int embed_dim, int in_chans, int patch_size);
+/* ... with `parts` parts per value: 1 as above, 3 = the exact fp32 split [Kp/32][3][embed][32] for vh_launch_patch_embed_planes3 */
+int vh_launch_conv_weight_planes_parts(vh_stream_t s, const float *conv_w, void *planes, int embed_dim, int in_chans, int patch_size,
+                                       int parts);
+/* The fp32 path's patch embedding on the planes kernel: the im2row producer writes the exact three-part split of the pixels
+ * (workspace: n_images*grid^2 * Kp * 6 bytes), six bf16 products per block as vh_launch_linear_p3 -- no operand is split inside
+ * a K loop.  Same arguments as vh_launch_patch_embed_planes. */
+int vh_launch_patch_embed_planes3(vh_stream_t s, const float *images, const void *conv_w_planes3, const float *conv_b,
+                                  const float *cls_token, const float *pos_embed, float *tokens, int n_images, int in_chans,
+                                  int img_size, int patch_size, int embed_dim, void *workspace, size_t workspace_bytes);
 int vh_launch_patch_embed_planes(vh_stream_t s, const float *images, const void *conv_w_planes, const float *conv_b,
                                  const float *cls_token, const float *pos_embed, float *tokens, int n_images,
                                  int in_chans, int img_size, int patch_size, int embed_dim, void *workspace,
@@ -271,6 +280,46 @@ int vh_launch_attention_planes_f16_mx(vh_stream_t s, const void *qkv_planes_f16,
 int vh_launch_linear_mx_planes_f16(vh_stream_t s, void *output_planes_f16, const void *weight_values,
                                    const void *weight_scales, const void *input_values, const void *input_scales,
                                    const float *bias, int rowA, int colA, int colB);
+
+/* ---- LayerNorm folded into the projection behind it (the reduced-precision modes; csrc/norm_fold.h) ----
+ * Replaces the `layerNorm` launches in front of the QKV projection and fc1 (layer_norm.cl:3-53; ViT_seq.c:120-142,346,358):
+ *     LN(x) W^T + b = rstd (x (gamma.W)^T - mean colsum(gamma.W)) + (beta W^T + b)
+ * The producers of the residual stream x -- patch embedding, output projection, fc2 -- leave x, besides the fp32 rows,
+ * as the next projection's operand (one-part bf16 planes, or an MX tensor) and, per row and 128 columns, the partial sums
+ * (sum x, sum x^2): row_stats[cols/128][rows][2] (no atomics: one writer per partial, fixed summation order).  The
+ * consuming projection multiplies the un-normalised rows by the gamma-scaled weights and applies the row terms in its
+ * epilogue; mean and 1/std are formed as layer_norm_seq forms them (eps added in double). */
+/* context-creation helpers: out[n][k] = weight[n][k] gamma[k];  out[n] = bias[n] + sum_k beta[k] weight[n][k];
+ * out[n] = sum_k of the operand's own (rounded / quantised) values of weight row n (scales NULL: one-part bf16 planes) */
+int vh_launch_fold_gamma(vh_stream_t s, const float *weight, const float *gamma, float *out, int out_features, int in_features);
+int vh_launch_fold_bias(vh_stream_t s, const float *weight, const float *beta, const float *bias, float *out, int out_features,
+                        int in_features);
+int vh_launch_colsum_operand(vh_stream_t s, const void *values, const void *scales, float *out, int out_features, int in_features);
+/* vh_launch_patch_embed_planes that also leaves the token rows (class-token rows included) as the first projection's
+ * operand -- one-part bf16 planes [embed/32][n*tokens][32], or MX values + scales when operand_scales_out != NULL -- and
+ * their partial sums row_stats_out [embed/128][n*tokens][2] */
+int vh_launch_patch_embed_planes_norm(vh_stream_t s, const float *images, const void *conv_w_planes, const float *conv_b,
+                                      const float *cls_token, const float *pos_embed, float *tokens, int n_images, int in_chans,
+                                      int img_size, int patch_size, int embed_dim, void *workspace, size_t workspace_bytes,
+                                      void *operand_out, void *operand_scales_out, float *row_stats_out);
+/* LN(A) W^T + b, folded: input_planes = the un-normalised rows (one-part bf16 planes), weight_planes = gamma-scaled.
+ * output_planes as vh_launch_linear_planes (0 fp32 rows, 1 bf16 planes, 2 fp16 planes); doGelu needs output_planes 1. */
+int vh_launch_linear_planes_norm(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
+                                 const void *input_planes, const float *row_stats, const float *colsum, const float *bias_folded,
+                                 double eps, int rowA, int colA, int colB, int doGelu);
+/* output = residual + A W^T + b (fp32 rows; in place allowed), the same rows as the next projection's operand (bf16
+ * planes, or MX when operand_scales_out != NULL) and their partial sums row_stats_out [colB/128][rowA][2] */
+int vh_launch_linear_planes_resid_norm(vh_stream_t s, float *output, const void *weight_planes, const void *input_planes,
+                                       const float *bias, const float *residual, int rowA, int colA, int colB,
+                                       void *operand_out, void *operand_scales_out, float *row_stats_out);
+/* the same two on block-scaled fp8 operands.  output_kind: 0 fp32 rows, 1 MX tensor (the only kind doGelu takes), 2 one-part
+ * fp16 planes */
+int vh_launch_linear_mx_norm(vh_stream_t s, void *output, void *output_scales, int output_kind, const void *weight_values,
+                             const void *weight_scales, const void *input_values, const void *input_scales, const float *row_stats,
+                             const float *colsum, const float *bias_folded, double eps, int rowA, int colA, int colB, int doGelu);
+int vh_launch_linear_mx_resid_norm(vh_stream_t s, float *output, const void *weight_values, const void *weight_scales,
+                                   const void *input_values, const void *input_scales, const float *bias, const float *residual,
+                                   int rowA, int colA, int colB, void *operand_values, void *operand_scales, float *row_stats_out);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,10 @@ Fixtures (inputs are regenerated from seeds, never stored):
                   IMAGE_COUNT (comparator.c:9) -- for synthetic images 0..99 on rounded weights, written
                   with Main.c's own arg-max loop (Main.c:59-71: pred_idx is NOT reset per image and class 0
                   is never visited, so the line is what the reference's Main.c would print around ViT_seq)
+  b16_real_image.npz  (`make_golden.py real_image`) the reference's ONE real input -- Data/input-1.bin, a normalised
+                  224x224 photograph (spatially correlated pixels, unlike every synthetic image) -- kept as a data fixture,
+                  with the logits / probabilities the reference's ViT_seq.c gives for it on the seed-0 synthetic weights
+                  (its pretrained answer Data/answer_result_1.txt cannot be reproduced: 36 weight files are absent)
 """
 from __future__ import annotations
 
@@ -85,9 +89,33 @@ def answers100(workers: int = 8) -> None:
     print("wrote b16_answer_result_100_rounded.txt; labels:", sorted(set(int(l.split()[2]) for l in main_c_lines(probs))))
 
 
+def real_image() -> None:
+    """Data/input-1.bin through the reference's ViT_seq.c on the seed-0 synthetic weights -> b16_real_image.npz."""
+    src = Path("/root/reference/MulticoreMainProject/Data/input-1.bin")
+    orc.build()
+    if not orc.have_reference() or not src.exists():
+        sys.exit("needs the build container (oracle/_ref/ref_harness and the reference's Data/input-1.bin)")
+    raw = src.read_bytes()
+    n, c, h, w = np.frombuffer(raw, dtype=np.int32, count=4)
+    assert (n, c, h, w) == (1, 3, 224, 224) and len(raw) == 16 + 4 * c * h * w
+    image = np.frombuffer(raw, dtype=np.float32, offset=16).reshape(c, h, w).copy()
+    with tempfile.TemporaryDirectory() as td:
+        rec = orc.run_reference("full_file", src, 0, out_path=Path(td) / "real.bin")
+    np.savez_compressed(GOLD / "b16_real_image.npz", image=image, logits=rec["logits"].reshape(1, 1000),
+                        probs=rec["probs"].reshape(1, 1000), seed_base=np.array(0),
+                        note=np.array("image = the reference's Data/input-1.bin (data, its only real input); logits/probs = "
+                                      "the reference's own ViT_seq.c on it with vit_synth_tensor weights, seed_base 0"))
+    lg = rec["logits"]
+    print("real image: mean %.3f std %.3f  argmax %d  top-2 margin %.4f" % (image.mean(), image.std(), int(lg.argmax()),
+                                                                           float(np.sort(lg)[-1] - np.sort(lg)[-2])))
+
+
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "answers100":
         answers100()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "real_image":
+        real_image()
         return
     orc.build()
     if not orc.have_reference():

@@ -9,6 +9,8 @@
  *                       like the reference loader does, Network.c:208-211: the file-based flow)
  *   ref_harness stages <seed_base> <out.bin>
  *   ref_harness time   <first_image> <count> <seed_base>       (prints seconds/image)
+ *   ref_harness full_file <images.bin> <seed_base> <out.bin>   (images from a file in the reference's own format,
+ *                       Network.c:41-71: int n, c, h, w, then n*c*h*w floats -- e.g. its Data/input-1.bin; synthetic weights)
  *
  * Logits are not observable through the reference's call surface
  * (ViT_seq.c:509-515 keeps them in a local).  The reference library is built
@@ -116,12 +118,39 @@ static ImageData *make_images(const vit_config *cfg, int first, int count)
     return im;
 }
 
+/* images from a file in the format of the reference's load_image_data (Network.c:41-71) */
+static ImageData *read_images(const vit_config *cfg, const char *path, int *count)
+{
+    FILE *f = fopen(path, "rb");
+    int hdr[4];
+    if (!f || fread(hdr, sizeof(int), 4, f) != 4 || hdr[0] <= 0 || hdr[1] != cfg->in_chans || hdr[2] != cfg->img_size ||
+        hdr[3] != cfg->img_size) {
+        fprintf(stderr, "ref_harness: %s is not an image file of this model's shape\n", path);
+        exit(2);
+    }
+    const size_t per = (size_t)hdr[1] * hdr[2] * hdr[3];
+    ImageData *im = (ImageData *)calloc((size_t)hdr[0], sizeof(ImageData));
+    for (int i = 0; i < hdr[0]; ++i) {
+        im[i].n = hdr[0]; im[i].c = hdr[1]; im[i].h = hdr[2]; im[i].w = hdr[3];
+        im[i].data = (float *)malloc(sizeof(float) * per);
+        if (fread(im[i].data, sizeof(float), per, f) != per) {
+            fprintf(stderr, "ref_harness: %s is truncated\n", path);
+            exit(2);
+        }
+    }
+    fclose(f);
+    *count = hdr[0];
+    return im;
+}
+
+static const char *g_image_file = NULL;
+
 static int run_full(int first, int count, unsigned long long seed_base, const char *out, int timing_only)
 {
     vit_config cfg;
     vit_config_preset(&cfg, "vit_b_16");
     Network *nets = make_weights(&cfg, seed_base);
-    ImageData *im = make_images(&cfg, first, count);
+    ImageData *im = g_image_file ? read_images(&cfg, g_image_file, &count) : make_images(&cfg, first, count);
     const int C = cfg.num_classes;
     float *logits = (float *)malloc(sizeof(float) * (size_t)count * C);
     float *probs = (float *)malloc(sizeof(float) * (size_t)count * C);
@@ -207,6 +236,10 @@ int main(int argc, char **argv)
     if (argc == 6 && strcmp(argv[1], "full_rounded") == 0) {
         g_round_weights = 1; /* weights as the reference's loader would deliver them from disk */
         return run_full(atoi(argv[2]), atoi(argv[3]), strtoull(argv[4], NULL, 10), argv[5], 0);
+    }
+    if (argc == 5 && strcmp(argv[1], "full_file") == 0) {
+        g_image_file = argv[2];
+        return run_full(0, 0, strtoull(argv[3], NULL, 10), argv[4], 0);
     }
     if (argc == 6 && strcmp(argv[1], "full") == 0)
         return run_full(atoi(argv[2]), atoi(argv[3]), strtoull(argv[4], NULL, 10), argv[5], 0);

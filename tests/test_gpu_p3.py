@@ -510,3 +510,38 @@ def test_patch_embed_on_one_part_planes_vs_oracle_on_bf16_rounded_operands(pkg, 
     for i in sorted({0, n // 2, n - 1}):
         want = orc.tokens_from_conv(orc.conv2d(_bf16_rne(imgs[i]), _bf16_rne(W[1]), W[2]), W[0], W[3])
         assert np.abs(got[i] - want).max() <= OP_TOL, f"image {i}"
+
+
+@pytest.mark.parametrize("preset,n", [("vit_b_16", 3), ("vit_h_14", 2), ("vit_b_16", 30)])
+def test_patch_embed_on_three_part_planes_vs_oracle_and_the_in_loop_split(pkg, device, preset, n):
+    """vh_launch_patch_embed_planes3 -- the fp32 path's conv_proj on the planes kernel (conv2d.cl:1-80): the im2row producer
+    writes the exact three-part split of the pixels, the GEMM forms the six products per block like every other fp32
+    projection.  Against the port's conv loop (ViT_seq.c:25-57) at the fp32 operator tolerance, and against round 1's
+    kernel that splits both operands inside its K loop (vh_launch_patch_embed_ws): the same products on the same k
+    assignment in the same order -- equal bit for bit."""
+    from oracle.oracle import Oracle
+    orc = Oracle(preset)
+    cfg = pkg.preset(preset)
+    E, T, P = cfg.embed_dim, pkg.binding.tokens(cfg), cfg.patch_size
+    W = [orc.synth_fill(orc.tensor_size(i), 40 + i, 0.05, 0.0) for i in range(4)]
+    imgs = pkg.synth_images(cfg, 20, n)
+    L = pkg.lib()
+    Kp = L.vh_patch_planes_k(3, P)
+    d = [_dev(pkg, a) for a in (imgs, W[1], W[2], W[0], W[3])]
+    d_wp = pkg.DeviceBuffer(E * Kp * 6 // 4)
+    _launch(pkg, "vh_launch_conv_weight_planes_parts", None, d[1].ptr, d_wp.ptr, E, 3, P, 3)
+    need = n * (T - 1) * Kp * 6
+    d_ws, d_tok = pkg.DeviceBuffer(need // 4), pkg.DeviceBuffer(n * T * E)
+    assert L.vh_launch_patch_embed_planes3(None, d[0].ptr, d_wp.ptr, d[2].ptr, d[3].ptr, d[4].ptr, d_tok.ptr, n, 3, 224, P, E,
+                                           d_ws.ptr, need - 16) != 0          # workspace too small
+    _launch(pkg, "vh_launch_patch_embed_planes3", None, d[0].ptr, d_wp.ptr, d[2].ptr, d[3].ptr, d[4].ptr, d_tok.ptr, n, 3, 224, P, E,
+            d_ws.ptr, need)
+    got = d_tok.to_numpy((n, T, E))
+    for i in sorted({0, n // 2, n - 1}):
+        want = orc.tokens_from_conv(orc.conv2d(imgs[i], W[1], W[2]), W[0], W[3])
+        assert np.abs(got[i] - want).max() <= OP_TOL, f"image {i}"
+    ws2 = L.vh_patch_embed_workspace(n, 3, 224, P, E)
+    d_ws2, d_tok2 = pkg.DeviceBuffer(max(ws2 // 4, 4)), pkg.DeviceBuffer(n * T * E)
+    _launch(pkg, "vh_launch_patch_embed_ws", None, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d_tok2.ptr, n, 3, 224, P, E,
+            d_ws2.ptr, ws2)
+    assert np.array_equal(got, d_tok2.to_numpy((n, T, E)))

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 OP_TOL = 2e-5
 LOGIT_TOL = 1e-4
+GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
 def _dev(pkg, a):
@@ -293,6 +294,33 @@ def test_model_logits_vs_reference_goldens(pkg, model, golden_full):
     assert np.array_equal(logits.argmax(1), golden_full["logits"].argmax(1))
     assert np.abs(probs - golden_full["probs"]).max() <= 1e-6
     assert np.abs(probs.sum(1) - 1.0).max() < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "fp8"])
+def test_model_on_the_references_real_image(pkg, device, weights, precision):
+    """The reference's one real input (Data/input-1.bin, kept as data in tests/golden/b16_real_image.npz: a normalised
+    photograph -- spatially correlated, every channel's mean well above zero -- where all other goldens are iid-uniform
+    pixels) against the logits the reference's own ViT_seq.c gives for it: the fp32 path within 1e-4 with the same
+    arg-max, the bf16 mode within its 4e-2, the fp8 mode within its relative L2 of 0.15."""
+    g = np.load(GOLDEN / "b16_real_image.npz")
+    cfg = pkg.preset("vit_b_16")
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=2, precision=precision)
+    logits, probs = m.forward(np.stack([g["image"], pkg.synth_images(cfg, 0, 1)[0]]))     # next to a synthetic neighbour
+    x = m.read_tokens(2)[:m.tokens].astype(np.float64)
+    m.close()
+    want = g["logits"][0]
+    err = float(np.abs(logits[0] - want).max())
+    rel = float(np.linalg.norm(logits[0] - want) / np.linalg.norm(want - want.mean()))
+    print(f"real image, {precision}: max |dlogit| {err:.3e}, relative L2 {rel:.4f}; its residual rows after the last layer: "
+          f"max |mean|/std {np.abs(x.mean(1) / x.std(1)).max():.3f}")
+    assert np.isfinite(logits).all() and abs(float(probs[0].sum()) - 1.0) < 1e-5
+    if precision == "f32":
+        assert err <= LOGIT_TOL and int(logits[0].argmax()) == int(want.argmax())
+        assert np.abs(probs[0] - g["probs"][0]).max() <= 1e-6
+    elif precision == "bf16":
+        assert err <= 4e-2
+    else:
+        assert rel <= 0.15
 
 
 def test_model_residual_stream_vs_oracle(pkg, model, oracle, weights):

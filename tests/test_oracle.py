@@ -4,7 +4,11 @@ REFERENCE ITSELF produced (oracle/make_golden.py ran the unmodified ViT_seq.c), 
 import numpy as np
 import pytest
 
+from pathlib import Path
+
 from oracle import oracle as orc
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
 def _check_summary(name, got, gold):
@@ -52,6 +56,16 @@ def test_full_model_bit_exact_vs_reference_goldens(oracle, weights, golden_full,
     assert np.array_equal(logits, golden_full["logits"][index])
     assert np.array_equal(probs, golden_full["probs"][index])
     assert abs(float(probs.sum()) - 1.0) < 1e-5
+
+
+def test_real_image_bit_exact_vs_reference_golden(oracle, weights):
+    """The reference's one real input (Data/input-1.bin: a normalised photograph, spatially correlated pixels with mean 1.2
+    and std 0.5 -- unlike the iid synthetic images) through the port equals, bit for bit, what the reference's own
+    ViT_seq.c gave for it on the same synthetic weights (tests/golden/b16_real_image.npz, oracle/make_golden.py real_image)."""
+    g = np.load(GOLDEN / "b16_real_image.npz")
+    assert g["image"].shape == (3, 224, 224) and g["image"].dtype == np.float32
+    logits, probs, _ = oracle.forward(np.ascontiguousarray(g["image"]), weights)
+    assert np.array_equal(logits, g["logits"][0]) and np.array_equal(probs, g["probs"][0])
 
 
 def test_answer_result_fixture_matches_goldens(golden_full):

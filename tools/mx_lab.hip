@@ -1,9 +1,9 @@
 /* mx_lab.hip -- throw-away ablations of the block-scaled fp8 GEMM kernel (csrc/gemm_mx.hip), all variants timed in
  * interleaved rounds inside one process on random operands (the method of tools/p3_lab.hip).  Not part of the library.
- *   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I include -I vit-with-opencl_amd/csrc \
+ *   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I include -I vit-with-opencl_amd/csrc -I tools \
  *         tools/mx_lab.hip vit-with-opencl_amd/csrc/kernelHandler.hip -o tools/mx_lab
  *   tools/mx_lab [M N K [resid]]      (default: the fc1 shape 100864 3072 768; "resid" = the fc2 / out-projection epilogue) */
-#include "../vit-with-opencl_amd/csrc/gemm_mx.hip"
+#include "mx_lab_kernel.inc"
 #include <cstdio>
 #include <vector>
 

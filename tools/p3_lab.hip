@@ -1,9 +1,9 @@
 /* p3_lab.hip -- throw-away ablations of the pre-split GEMM kernel (csrc/gemm_p3.hip), all variants timed
  * in interleaved rounds inside one process on random operands (guide rules 24/25).  Not part of the library.
- *   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I include -I vit-with-opencl_amd/csrc \
+ *   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I include -I vit-with-opencl_amd/csrc -I tools \
  *         tools/p3_lab.hip vit-with-opencl_amd/csrc/kernelHandler.hip -o tools/p3_lab
  *   tools/p3_lab [M N K]      (default: the fc1 shape 98304 3072 768) */
-#include "../vit-with-opencl_amd/csrc/gemm_p3.hip"
+#include "p3_lab_kernel.inc"
 #include <cmath>
 #include <cstdio>
 #include <vector>

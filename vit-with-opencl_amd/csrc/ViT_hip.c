@@ -59,9 +59,15 @@ struct vit_hip_ctx
     /* FP8_GEMM: block-scaled e4m3 copies of the same four matrices (values, then their e8m0 block scales) */
     void *w8_slab;
     void **w8, **w8s;   /* per tensor index: values, scales */
-    /* BF16_GEMM / FP8_GEMM: conv_proj as one-part bf16 planes [Kp/32][1][E][32] (vh_launch_patch_embed_planes) */
+    /* conv_proj as planes [Kp/32][parts][E][32]: one part (bf16) for BF16_GEMM / FP8_GEMM (vh_launch_patch_embed_planes),
+     * the exact three-part split for the fp32 path on planes (vh_launch_patch_embed_planes3) */
     void *wconv16;
-    size_t w_slab_bytes, planes_bytes, wconv16_bytes;   /* sizes of w_slab, of the mode's repacked slab, of wconv16 */
+    /* BF16_GEMM / FP8_GEMM with the LayerNorms folded into the projections behind them (csrc/norm_fold.h): the QKV and fc1
+     * operand copies hold gamma-scaled weights; per such matrix, colsum [N] of the rounded values and the folded bias [N] */
+    int ln_fold;
+    float *fold_slab;
+    float **fold_cs, **fold_b;   /* per tensor index (in_proj and fc1 weights only) */
+    size_t w_slab_bytes, planes_bytes, wconv16_bytes, fold_bytes;   /* sizes of w_slab, of the mode's repacked slab, of wconv16, of fold_slab */
 
     /* activation arena (rows = max_batch * tokens) */
     float *x;           /* residual stream      [rows][E]   */
@@ -70,6 +76,7 @@ struct vit_hip_ctx
     float *qkv;         /* fused Q|K|V          [rows][3E]  */
     float *hid;         /* MLP hidden           [rows][F]   */
     size_t ws_bytes;    /* size of hid, which doubles as the patch-gather workspace */
+    float *stats;       /* ln_fold: partial (sum, sum of squares) of the residual rows, [E/128][rows][2] */
     float *cls;         /* normalised CLS rows  [max_batch][E] */
     float *d_logits;    /* [max_batch][classes] */
     float *d_probs;     /* [max_batch][classes] */
@@ -170,7 +177,9 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
         vh_free(ctx->wconv16);
     free(ctx->w8);
     free(ctx->w8s);
-    float *dev[] = {ctx->w_slab, ctx->x, ctx->y, ctx->attn, ctx->qkv, ctx->hid,
+    free(ctx->fold_cs);
+    free(ctx->fold_b);
+    float *dev[] = {ctx->w_slab, ctx->x, ctx->y, ctx->attn, ctx->qkv, ctx->hid, ctx->fold_slab, ctx->stats,
                     ctx->cls, ctx->d_logits, ctx->d_probs, ctx->d_images[0], ctx->d_images[1]};
     for (size_t i = 0; i < sizeof(dev) / sizeof(dev[0]); ++i)
         if (dev[i])
@@ -207,16 +216,42 @@ static size_t repack_bytes_per_weight(const vit_hip_ctx *ctx)
     }
 }
 
-/* Allocate the weight slabs and fix every tensor's place in them.  Depends on (cfg, precision) only, so a planes file
- * written by one context (vit_hip_export_planes) drops into another's slabs byte for byte. */
+/* The sizes of a context's weight slabs: w_slab, the mode's repacked slab, wconv16, fold_slab.  A function of (cfg,
+ * precision, ln_fold) alone and free of side effects: vit_hip_create_from_planes checks a file's header against it
+ * BEFORE anything is allocated. */
+static void weight_slab_sizes(const vit_hip_ctx *ctx, size_t sizes[4])
+{
+    const vit_config *cfg = &ctx->cfg;
+    size_t total = 0;
+    for (int i = 0; i < ctx->n_tensors; ++i)
+        total += align_up(vit_config_tensor_size(cfg, i) * sizeof(float), 256);
+    const size_t per = repack_bytes_per_weight(ctx);
+    size_t planes = 0, fold = 0;
+    for (int l = 0; l < cfg->depth; ++l)
+        for (int k = 0; k < 4; ++k) {
+            const size_t cnt = vit_config_tensor_size(cfg, 4 + 12 * l + BIG[k]);
+            planes += ctx->precision == VIT_PRECISION_FP8_GEMM ? align_up(cnt, 256) + align_up(cnt / 32, 256) : align_up(cnt * per, 256);
+            if (ctx->ln_fold && (k == 0 || k == 2))   /* in_proj and fc1: colsum and folded bias, one float per output feature each */
+                fold += 2 * align_up(vit_config_tensor_size(cfg, 4 + 12 * l + BIG[k] + 1) * sizeof(float), 256);
+        }
+    sizes[0] = total;
+    sizes[1] = planes;
+    const size_t conv_parts = (ctx->precision == VIT_PRECISION_BF16_GEMM || ctx->precision == VIT_PRECISION_FP8_GEMM) ? 1
+                            : (ctx->precision == VIT_PRECISION_F32 && per == 6) ? 3 : 0;
+    sizes[2] = cfg->embed_dim % 128 == 0 ? (size_t)vh_patch_planes_k(cfg->in_chans, cfg->patch_size) * (size_t)cfg->embed_dim * 2 * conv_parts : 0;
+    sizes[3] = fold;
+}
+
+/* Allocate the weight slabs and fix every tensor's place in them.  Depends on (cfg, precision, ln_fold) only, so a planes
+ * file written by one context (vit_hip_export_planes) drops into another's slabs byte for byte. */
 static int layout_weights(vit_hip_ctx *ctx)
 {
     int rc = 0;
     const vit_config *cfg = &ctx->cfg;
     const int n_tensors = ctx->n_tensors;
-    size_t total = 0;
-    for (int i = 0; i < n_tensors; ++i)
-        total += align_up(vit_config_tensor_size(cfg, i) * sizeof(float), 256);
+    size_t sizes[4];
+    weight_slab_sizes(ctx, sizes);
+    const size_t total = sizes[0], planes = sizes[1];
     ctx->w_slab_bytes = total;
     TRY(vh_malloc((void **)&ctx->w_slab, total));
     size_t off = 0;
@@ -225,13 +260,20 @@ static int layout_weights(vit_hip_ctx *ctx)
         off += align_up(vit_config_tensor_size(cfg, i) * sizeof(float), 256);
     }
     const size_t per = repack_bytes_per_weight(ctx);
-    size_t planes = 0;
-    for (int l = 0; l < cfg->depth; ++l)
-        for (int k = 0; k < 4; ++k) {
-            const size_t cnt = vit_config_tensor_size(cfg, 4 + 12 * l + BIG[k]);
-            planes += ctx->precision == VIT_PRECISION_FP8_GEMM ? align_up(cnt, 256) + align_up(cnt / 32, 256) : align_up(cnt * per, 256);
-        }
     ctx->planes_bytes = planes;
+    ctx->fold_bytes = sizes[3];
+    if (ctx->fold_bytes) {
+        TRY(vh_malloc((void **)&ctx->fold_slab, ctx->fold_bytes));
+        size_t fo = 0;
+        for (int l = 0; l < cfg->depth; ++l)
+            for (int k = 0; k < 4; k += 2) {
+                const int idx = 4 + 12 * l + BIG[k];
+                const size_t nb = align_up(vit_config_tensor_size(cfg, idx + 1) * sizeof(float), 256);
+                ctx->fold_cs[idx] = (float *)((char *)ctx->fold_slab + fo);
+                ctx->fold_b[idx] = (float *)((char *)ctx->fold_slab + fo + nb);
+                fo += 2 * nb;
+            }
+    }
     if (planes) {
         void *slab = NULL;
         TRY(vh_malloc(&slab, planes));
@@ -260,9 +302,9 @@ static int layout_weights(vit_hip_ctx *ctx)
                 }
             }
     }
-    if ((ctx->precision == VIT_PRECISION_BF16_GEMM || ctx->precision == VIT_PRECISION_FP8_GEMM) && cfg->embed_dim % 128 == 0) {
+    if (sizes[2]) {
         /* the reduced modes' patch embedding: conv weights rounded to bf16 planes, K padded to the one-part K step */
-        ctx->wconv16_bytes = (size_t)vh_patch_planes_k(cfg->in_chans, cfg->patch_size) * (size_t)cfg->embed_dim * 2;
+        ctx->wconv16_bytes = sizes[2];
         TRY(vh_malloc(&ctx->wconv16, ctx->wconv16_bytes));
     }
     return 0;
@@ -277,14 +319,33 @@ static int fill_weights(vit_hip_ctx *ctx, const Network *networks)
     const vit_config *cfg = &ctx->cfg;
     for (int i = 0; i < ctx->n_tensors; ++i)
         TRY(vh_h2d(ctx->w[i], networks[i].data, networks[i].size * sizeof(float), ctx->stream));
-    float *d_amax = NULL;
+    float *d_amax = NULL, *d_scaled = NULL;
     if (ctx->precision == VIT_PRECISION_F32_FP16X2)
         TRY(vh_malloc((void **)&d_amax, sizeof(float)));
+    if (ctx->ln_fold)   /* gamma-scaled copy of one matrix at a time, before its rounding (the largest is fc1 / in_proj) */
+        TRY(vh_malloc((void **)&d_scaled, (size_t)cfg->embed_dim * (size_t)(cfg->mlp_hidden > 3 * cfg->embed_dim ? cfg->mlp_hidden : 3 * cfg->embed_dim) * sizeof(float)));
     for (int l = 0; l < cfg->depth && rc == 0; ++l)
         for (int k = 0; k < 4 && rc == 0; ++k) {
             const int idx = 4 + 12 * l + BIG[k];
             const int out_f = (int)networks[idx + 1].size, in_f = (int)(networks[idx].size / networks[idx + 1].size);
-            if (ctx->precision == VIT_PRECISION_BF16_GEMM) {
+            if (ctx->ln_fold && (k == 0 || k == 2)) {
+                /* the LayerNorm in front of this projection moves into it (csrc/norm_fold.h): W' = gamma . W rounded to the
+                 * mode's operand format, colsum of the ROUNDED values, bias' = bias + beta W^T from the fp32 weights.
+                 * ln1 (tensors 0, 1 of the layer) feeds in_proj, ln2 (6, 7) feeds fc1. */
+                const float *gamma = ctx->w[4 + 12 * l + (k == 0 ? 0 : 6)], *beta = ctx->w[4 + 12 * l + (k == 0 ? 1 : 7)];
+                if ((rc = vh_launch_fold_gamma(ctx->stream, ctx->w[idx], gamma, d_scaled, out_f, in_f)) != 0)
+                    break;
+                if (ctx->precision == VIT_PRECISION_BF16_GEMM)
+                    rc = vh_launch_split_rows(ctx->stream, d_scaled, ctx->w16[idx], out_f, in_f, 1);
+                else
+                    rc = vh_launch_quantize_mx_rows(ctx->stream, d_scaled, ctx->w8[idx], ctx->w8s[idx], out_f, in_f);
+                if (rc == 0)
+                    rc = ctx->precision == VIT_PRECISION_BF16_GEMM
+                             ? vh_launch_colsum_operand(ctx->stream, ctx->w16[idx], NULL, ctx->fold_cs[idx], out_f, in_f)
+                             : vh_launch_colsum_operand(ctx->stream, ctx->w8[idx], ctx->w8s[idx], ctx->fold_cs[idx], out_f, in_f);
+                if (rc == 0)
+                    rc = vh_launch_fold_bias(ctx->stream, ctx->w[idx], beta, ctx->w[idx + 1], ctx->fold_b[idx], out_f, in_f);
+            } else if (ctx->precision == VIT_PRECISION_BF16_GEMM) {
                 /* one-part planes [K/32][1][N][32] (gemm_p3.hip); everything else (norms, biases, embeddings, classifier) stays fp32 */
                 rc = vh_launch_split_rows(ctx->stream, ctx->w[idx], ctx->w16[idx], out_f, in_f, 1);
             } else if (ctx->precision == VIT_PRECISION_F32 && ctx->w3_slab) {
@@ -311,14 +372,24 @@ static int fill_weights(vit_hip_ctx *ctx, const Network *networks)
                 rc = vh_launch_split2h_planes(ctx->stream, ctx->w[idx], ctx->w3[idx], out_f, in_f, scale);
             }
         }
+    if (rc == 0 && d_scaled)
+        rc = vh_stream_sync(ctx->stream);   /* the scratch copy is freed below */
     if (d_amax)
         vh_free(d_amax);
+    if (d_scaled)
+        vh_free(d_scaled);
+    d_amax = d_scaled = NULL;
     if (rc)
         return rc;
     if (ctx->wconv16)
-        TRY(vh_launch_conv_weight_planes(ctx->stream, ctx->w[1], ctx->wconv16, cfg->embed_dim, cfg->in_chans, cfg->patch_size));
+        TRY(vh_launch_conv_weight_planes_parts(ctx->stream, ctx->w[1], ctx->wconv16, cfg->embed_dim, cfg->in_chans, cfg->patch_size,
+                                               ctx->precision == VIT_PRECISION_F32 ? 3 : 1));
     return 0;
 fail:
+    if (d_amax)
+        vh_free(d_amax);
+    if (d_scaled)
+        vh_free(d_scaled);
     return rc;
 }
 
@@ -340,9 +411,22 @@ int vit_hip_create(vit_hip_ctx **out, const vit_config *cfg, const Network *netw
 }
 
 int vit_hip_precision(const vit_hip_ctx *ctx) { return ctx->precision; }
+int vit_hip_ln_fold(const vit_hip_ctx *ctx) { return ctx ? ctx->ln_fold : 0; }
+
+/* The reduced modes fold every LayerNorm but the final one into the projection behind it (csrc/norm_fold.h) unless
+ * $VIT_HIP_LN_FOLD=0 (the separate LayerNorm launches of rounds 1-3: the A/B of tests and bench).  The fp32 paths never fold. */
+static int want_ln_fold(const vit_config *cfg, int precision)
+{
+    const char *env = getenv("VIT_HIP_LN_FOLD");
+    if (precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM)
+        return 0;
+    if (env && env[0] == '0')
+        return 0;
+    return cfg->embed_dim % 128 == 0 && (long)cfg->embed_dim / 128 <= 64;
+}
 
 /* Argument checks shared by both ways of making a context, and the empty context itself. */
-static int ctx_new(vit_hip_ctx **out, const vit_config *cfg, int n_tensors, int device, int max_batch, int precision)
+static int ctx_new(vit_hip_ctx **out, const vit_config *cfg, int n_tensors, int device, int max_batch, int precision, int ln_fold)
 {
     if (!out)
         return 1;
@@ -361,9 +445,15 @@ static int ctx_new(vit_hip_ctx **out, const vit_config *cfg, int n_tensors, int 
     if (cfg->depth <= 0 || cfg->embed_dim <= 0 || cfg->num_heads <= 0 || cfg->patch_size <= 0 || cfg->img_size <= 0 ||
         cfg->in_chans <= 0 || cfg->num_classes <= 0 || cfg->mlp_hidden <= 0)
         return 2;
+    /* sane sizes: what a context may be asked to allocate is bounded whatever a caller or a file header says */
+    if (cfg->depth > 256 || cfg->embed_dim > 16384 || cfg->mlp_hidden > 65536 || cfg->img_size > 4096 || cfg->in_chans > 64 ||
+        cfg->num_classes > (1 << 20) || cfg->num_heads > 1024 || max_batch > (1 << 20))
+        return 2;
     if (n_tensors != vit_config_num_tensors(cfg))
         return 2;
     if (cfg->embed_dim % cfg->num_heads != 0 || cfg->img_size % cfg->patch_size != 0)
+        return 2;
+    if (ln_fold && ((precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM) || cfg->embed_dim % 128 != 0))
         return 2;
     vit_hip_ctx *ctx = (vit_hip_ctx *)calloc(1, sizeof(*ctx));
     if (!ctx)
@@ -374,13 +464,18 @@ static int ctx_new(vit_hip_ctx **out, const vit_config *cfg, int n_tensors, int 
     ctx->tokens = vit_config_tokens(cfg);
     ctx->n_tensors = n_tensors;
     ctx->precision = precision;
+    ctx->ln_fold = ln_fold;
+    ctx->fold_cs = (float **)calloc((size_t)n_tensors, sizeof(float *));
+    ctx->fold_b = (float **)calloc((size_t)n_tensors, sizeof(float *));
     ctx->w = (float **)calloc((size_t)n_tensors, sizeof(float *));
     ctx->w16 = (void **)calloc((size_t)n_tensors, sizeof(void *));
     ctx->w3 = (void **)calloc((size_t)n_tensors, sizeof(void *));
     ctx->w3_scale = (float *)calloc((size_t)n_tensors, sizeof(float));
     ctx->w8 = (void **)calloc((size_t)n_tensors, sizeof(void *));
     ctx->w8s = (void **)calloc((size_t)n_tensors, sizeof(void *));
-    if (!ctx->w || !ctx->w16 || !ctx->w3 || !ctx->w3_scale || !ctx->w8 || !ctx->w8s) {
+    if (!ctx->w || !ctx->w16 || !ctx->w3 || !ctx->w3_scale || !ctx->w8 || !ctx->w8s || !ctx->fold_cs || !ctx->fold_b) {
+        free(ctx->fold_cs);
+        free(ctx->fold_b);
         free(ctx->w);
         free(ctx->w16);
         free(ctx->w3);
@@ -414,7 +509,7 @@ int vit_hip_create_ex(vit_hip_ctx **out, const vit_config *cfg, const Network *n
             return 3;
         }
     vit_hip_ctx *ctx = NULL;
-    if ((rc = ctx_new(&ctx, cfg, n_tensors, device, max_batch, precision)) != 0)
+    if ((rc = ctx_new(&ctx, cfg, n_tensors, device, max_batch, precision, want_ln_fold(cfg, precision))) != 0)
         return rc;
     TRY(vh_init(device));
     TRY(vh_stream_create(&ctx->stream));
@@ -436,17 +531,37 @@ fail:
  * layouts follow from (config, precision) alone (layout_weights), so vit_hip_create_from_planes is three reads into
  * three allocations: no fp32 -> format pass, no per-tensor files (the reference's loader opens 152 of them,
  * Network.c:134-218). */
+/* Bumped whenever a repack kernel changes what it writes for the same (config, precision): the slab sizes alone would
+ * not notice (csrc/gemm_p3.hip planes, csrc/gemm_mx.hip MX values / scale order, the fold terms of csrc/norm_fold.h). */
+#define VIT_PLANES_LAYOUT_VERSION 2
+
 struct planes_header
 {
-    char magic[8];                 /* "VITPLN01" */
+    char magic[8];                 /* "VITPLN02" */
     unsigned header_bytes;
     int precision, n_tensors;
     int cfg_ints[8];               /* img, patch, chans, classes, embed, depth, heads, mlp_hidden */
     double eps;
     unsigned long long w_slab_bytes, planes_bytes, wconv16_bytes, scale_floats;   /* scale_floats = n_tensors (w3_scale) */
+    unsigned long long fold_bytes; /* colsum + folded bias of the gamma-scaled matrices (ln_fold) */
+    int ln_fold, layout_version;
+    unsigned long long checksum;   /* of everything behind the header, in file order (planes_hash) */
 };
 
-static int copy_file_and_device(vit_hip_ctx *ctx, FILE *fp, void *dev, size_t bytes, int to_file)
+/* FNV-1a over 64-bit words (the payload slabs are all multiples of 8 bytes; a tail is taken byte-wise) */
+static unsigned long long planes_hash(unsigned long long h, const void *data, size_t bytes)
+{
+    const unsigned long long *w = (const unsigned long long *)data;
+    for (size_t i = 0; i < bytes / 8; ++i)
+        h = (h ^ w[i]) * 0x100000001b3ull;
+    const unsigned char *t = (const unsigned char *)data + (bytes & ~(size_t)7);
+    for (size_t i = 0; i < (bytes & 7); ++i)
+        h = (h ^ t[i]) * 0x100000001b3ull;
+    return h;
+}
+#define PLANES_HASH_SEED 0xcbf29ce484222325ull
+
+static int copy_file_and_device(vit_hip_ctx *ctx, FILE *fp, void *dev, size_t bytes, int to_file, unsigned long long *hash)
 {
     enum { CHUNK = 64 << 20 };
     int rc = 0;
@@ -459,6 +574,7 @@ static int copy_file_and_device(vit_hip_ctx *ctx, FILE *fp, void *dev, size_t by
         if (to_file) {
             if ((rc = vh_d2h(host, (char *)dev + off, n, ctx->stream)) != 0 || (rc = vh_stream_sync(ctx->stream)) != 0)
                 break;
+            *hash = planes_hash(*hash, host, n);
             if (fwrite(host, 1, n, fp) != n)
                 rc = vh_set_error(120, "vit_hip_export_planes: short write");
         } else {
@@ -466,6 +582,7 @@ static int copy_file_and_device(vit_hip_ctx *ctx, FILE *fp, void *dev, size_t by
                 rc = vh_set_error(121, "vit_hip_create_from_planes: file is shorter than its header says");
                 break;
             }
+            *hash = planes_hash(*hash, host, n);
             if ((rc = vh_h2d((char *)dev + off, host, n, ctx->stream)) != 0 || (rc = vh_stream_sync(ctx->stream)) != 0)
                 break;
         }
@@ -481,18 +598,28 @@ static void *planes_slab(const vit_hip_ctx *ctx)
     return ctx->precision == VIT_PRECISION_BF16_GEMM ? ctx->w16_slab : ctx->precision == VIT_PRECISION_FP8_GEMM ? ctx->w8_slab : ctx->w3_slab;
 }
 
+/* Written to `path`.tmp and renamed over `path` when complete: an interrupted export never leaves a truncated file
+ * under the name a later run will open. */
 int vit_hip_export_planes(vit_hip_ctx *ctx, const char *path)
 {
     int rc = 0;
     if (!ctx || !path)
         return vh_set_error(1, "vit_hip_export_planes: null argument");
     TRY(vh_set_device(ctx->device));
-    FILE *fp = fopen(path, "wb");
-    if (!fp)
+    const size_t plen = strlen(path);
+    char *tmp = (char *)malloc(plen + 5);
+    if (!tmp)
+        return vh_set_error(4, "vit_hip_export_planes: out of host memory");
+    memcpy(tmp, path, plen);
+    memcpy(tmp + plen, ".tmp", 5);
+    FILE *fp = fopen(tmp, "wb");
+    if (!fp) {
+        free(tmp);
         return vh_set_error(122, "vit_hip_export_planes: cannot open the file for writing");
+    }
     struct planes_header h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "VITPLN01", 8);
+    memcpy(h.magic, "VITPLN02", 8);
     h.header_bytes = (unsigned)sizeof(h);
     h.precision = ctx->precision;
     h.n_tensors = ctx->n_tensors;
@@ -503,17 +630,34 @@ int vit_hip_export_planes(vit_hip_ctx *ctx, const char *path)
     h.w_slab_bytes = ctx->w_slab_bytes;
     h.planes_bytes = ctx->planes_bytes;
     h.wconv16_bytes = ctx->wconv16_bytes;
+    h.fold_bytes = ctx->fold_bytes;
+    h.ln_fold = ctx->ln_fold;
+    h.layout_version = VIT_PLANES_LAYOUT_VERSION;
     h.scale_floats = (unsigned long long)ctx->n_tensors;
+    unsigned long long hash = planes_hash(PLANES_HASH_SEED, ctx->w3_scale, sizeof(float) * (size_t)ctx->n_tensors);
+    /* the header goes first with a zero checksum and is rewritten once the payload has been hashed */
     if (fwrite(&h, sizeof(h), 1, fp) != 1 || fwrite(ctx->w3_scale, sizeof(float), (size_t)ctx->n_tensors, fp) != (size_t)ctx->n_tensors)
         rc = vh_set_error(120, "vit_hip_export_planes: short write");
     if (rc == 0)
-        rc = copy_file_and_device(ctx, fp, ctx->w_slab, ctx->w_slab_bytes, 1);
+        rc = copy_file_and_device(ctx, fp, ctx->w_slab, ctx->w_slab_bytes, 1, &hash);
     if (rc == 0)
-        rc = copy_file_and_device(ctx, fp, planes_slab(ctx), ctx->planes_bytes, 1);
+        rc = copy_file_and_device(ctx, fp, planes_slab(ctx), ctx->planes_bytes, 1, &hash);
     if (rc == 0)
-        rc = copy_file_and_device(ctx, fp, ctx->wconv16, ctx->wconv16_bytes, 1);
+        rc = copy_file_and_device(ctx, fp, ctx->wconv16, ctx->wconv16_bytes, 1, &hash);
+    if (rc == 0)
+        rc = copy_file_and_device(ctx, fp, ctx->fold_slab, ctx->fold_bytes, 1, &hash);
+    if (rc == 0) {
+        h.checksum = hash;
+        if (fseek(fp, 0, SEEK_SET) != 0 || fwrite(&h, sizeof(h), 1, fp) != 1)
+            rc = vh_set_error(120, "vit_hip_export_planes: short write");
+    }
     if (fclose(fp) != 0 && rc == 0)
         rc = vh_set_error(120, "vit_hip_export_planes: short write");
+    if (rc == 0 && rename(tmp, path) != 0)
+        rc = vh_set_error(122, "vit_hip_export_planes: cannot move the finished file into place");
+    if (rc != 0)
+        remove(tmp);
+    free(tmp);
     return rc;
 fail:
     return rc;
@@ -532,31 +676,44 @@ int vit_hip_create_from_planes(vit_hip_ctx **out, const char *path, int device, 
         return vh_set_error(123, "vit_hip_create_from_planes: cannot open the file");
     struct planes_header h;
     vit_hip_ctx *ctx = NULL;
-    if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, "VITPLN01", 8) != 0 || h.header_bytes != sizeof(h)) {
+    if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, "VITPLN02", 8) != 0 || h.header_bytes != sizeof(h) ||
+        h.layout_version != VIT_PLANES_LAYOUT_VERSION) {
         fclose(fp);
-        return vh_set_error(124, "vit_hip_create_from_planes: not a planes file of this library version");
+        return vh_set_error(124, "vit_hip_create_from_planes: not a planes file of this library version (magic, header size or operand-layout version)");
     }
     vit_config cfg = {h.cfg_ints[0], h.cfg_ints[1], h.cfg_ints[2], h.cfg_ints[3], h.cfg_ints[4], h.cfg_ints[5], h.cfg_ints[6],
                       h.cfg_ints[7], h.eps};
-    if ((rc = ctx_new(&ctx, &cfg, h.n_tensors, device, max_batch, h.precision)) != 0) {
+    /* ctx_new bounds every dimension and allocates only the per-tensor pointer tables (n_tensors is tied to depth) */
+    if (h.n_tensors <= 0 || h.n_tensors > 4 + 12 * 256 + 4 ||
+        (rc = ctx_new(&ctx, &cfg, h.n_tensors, device, max_batch, h.precision, h.ln_fold ? 1 : 0)) != 0) {
         fclose(fp);
-        return vh_set_error(rc, "vit_hip_create_from_planes: the header's model shape or precision is not one this library takes");
+        return vh_set_error(rc ? rc : 2, "vit_hip_create_from_planes: the header's model shape or precision is not one this library takes");
     }
-    if (h.scale_floats != (unsigned long long)ctx->n_tensors ||
-        fread(ctx->w3_scale, sizeof(float), (size_t)ctx->n_tensors, fp) != (size_t)ctx->n_tensors) {
+    {   /* the slab sizes this library derives from (shape, precision, fold) against the header's, BEFORE anything is allocated */
+        size_t sizes[4];
+        weight_slab_sizes(ctx, sizes);
+        if (h.w_slab_bytes != sizes[0] || h.planes_bytes != sizes[1] || h.wconv16_bytes != sizes[2] || h.fold_bytes != sizes[3] ||
+            h.scale_floats != (unsigned long long)ctx->n_tensors) {
+            rc = vh_set_error(125, "vit_hip_create_from_planes: slab sizes in the file do not match this library's layout");
+            goto fail;
+        }
+    }
+    if (fread(ctx->w3_scale, sizeof(float), (size_t)ctx->n_tensors, fp) != (size_t)ctx->n_tensors) {
         rc = vh_set_error(124, "vit_hip_create_from_planes: truncated header");
         goto fail;
     }
+    unsigned long long hash = planes_hash(PLANES_HASH_SEED, ctx->w3_scale, sizeof(float) * (size_t)ctx->n_tensors);
     TRY(vh_init(device));
     TRY(vh_stream_create(&ctx->stream));
     TRY(layout_weights(ctx));
-    if (h.w_slab_bytes != ctx->w_slab_bytes || h.planes_bytes != ctx->planes_bytes || h.wconv16_bytes != ctx->wconv16_bytes) {
-        rc = vh_set_error(125, "vit_hip_create_from_planes: slab sizes in the file do not match this library's layout");
+    TRY(copy_file_and_device(ctx, fp, ctx->w_slab, ctx->w_slab_bytes, 0, &hash));
+    TRY(copy_file_and_device(ctx, fp, planes_slab(ctx), ctx->planes_bytes, 0, &hash));
+    TRY(copy_file_and_device(ctx, fp, ctx->wconv16, ctx->wconv16_bytes, 0, &hash));
+    TRY(copy_file_and_device(ctx, fp, ctx->fold_slab, ctx->fold_bytes, 0, &hash));
+    if (hash != h.checksum) {
+        rc = vh_set_error(126, "vit_hip_create_from_planes: payload checksum mismatch (corrupt file)");
         goto fail;
     }
-    TRY(copy_file_and_device(ctx, fp, ctx->w_slab, ctx->w_slab_bytes, 0));
-    TRY(copy_file_and_device(ctx, fp, planes_slab(ctx), ctx->planes_bytes, 0));
-    TRY(copy_file_and_device(ctx, fp, ctx->wconv16, ctx->wconv16_bytes, 0));
     TRY(alloc_arena(ctx));
     fclose(fp);
     *out = ctx;
@@ -599,6 +756,8 @@ static int alloc_arena(vit_hip_ctx *ctx)
         ctx->ws_bytes = ws > hid_bytes ? ws : hid_bytes;
         TRY(vh_malloc((void **)&ctx->hid, ctx->ws_bytes));
     }
+    if (ctx->ln_fold)
+        TRY(vh_malloc((void **)&ctx->stats, rows * (E / 128) * 2 * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->cls, (size_t)max_batch * E * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->d_logits, (size_t)max_batch * NC * sizeof(float)));
     TRY(vh_malloc((void **)&ctx->d_probs, (size_t)max_batch * NC * sizeof(float)));
@@ -632,9 +791,20 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     float **w = ctx->w;
 
     /* patch embedding + class token + position embedding (ViT_seq.c:437-443) */
-    if (ctx->wconv16)   /* reduced modes: im2row to one-part planes (in the MLP buffer, idle here) + the planes GEMM */
+    const int fold = ctx->ln_fold;
+    /* ln_fold (reduced modes): y holds the residual rows x as the next projection's operand -- one-part bf16 planes, or MX
+     * values with their scales behind them -- and stats their partial sums; both are written by whoever writes x */
+    char *const y_scales = (char *)ctx->y + align_up((size_t)rows * E, 256);
+    if (fold)
+        OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_planes_norm(s, d_images, ctx->wconv16, w[2], w[0], w[3], ctx->x, n, c->in_chans,
+                                                                 c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes, ctx->y,
+                                                                 ctx->precision == VIT_PRECISION_FP8_GEMM ? y_scales : NULL, ctx->stats));
+    else if (ctx->wconv16 && ctx->precision != VIT_PRECISION_F32)   /* reduced modes: im2row to one-part planes (in the MLP buffer, idle here) + the planes GEMM */
         OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_planes(s, d_images, ctx->wconv16, w[2], w[0], w[3], ctx->x, n, c->in_chans,
                                                             c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
+    else if (ctx->wconv16 && ctx->use_p3)   /* the fp32 path on planes: im2row writes the exact three-part split, six products per block */
+        OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_planes3(s, d_images, ctx->wconv16, w[2], w[0], w[3], ctx->x, n, c->in_chans,
+                                                             c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
     else
         OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_ws(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n, c->in_chans,
                                                         c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
@@ -649,6 +819,35 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         void **l8 = ctx->w8 + 4 + 12 * l, **l8s = ctx->w8s + 4 + 12 * l;
         char *ys = (char *)ctx->y + align_up((size_t)rows * E, 256), *as_ = (char *)ctx->attn + align_up((size_t)rows * E, 256);
         char *hs = (char *)ctx->hid + align_up((size_t)rows * F, 256);
+        if (fold) {
+            /* LayerNorms folded (csrc/norm_fold.h): ctx->y / ys = MX(x) and ctx->stats come from the patch embedding or the
+             * previous layer's fc2; QKV and fc1 apply the row terms in their epilogues; out-proj and fc2 refresh both */
+            const float *cs_in = ctx->fold_cs[4 + 12 * l + 2], *bf_in = ctx->fold_b[4 + 12 * l + 2];
+            const float *cs_f1 = ctx->fold_cs[4 + 12 * l + 8], *bf_f1 = ctx->fold_b[4 + 12 * l + 8];
+            const int planes_qkv = (E == 64 * c->num_heads && T <= 208) || (E == 80 * c->num_heads && T <= 272);
+            OP(VIT_OP_QKV, vh_launch_linear_mx_norm(s, ctx->qkv, NULL, planes_qkv ? 2 : 0, l8[2], l8s[2], ctx->y, ys, ctx->stats, cs_in,
+                                                    bf_in, c->eps, rows, E, 3 * E, 0));
+            if (E == 64 * c->num_heads && T <= 208)
+                OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16_mx(s, ctx->qkv, ctx->attn, as_, n, T, E, c->num_heads));
+            else if (planes_qkv)
+                OP(VIT_OP_ATTENTION, (c->num_heads & 1) == 0
+                       ? vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, as_, 2, n, T, E, c->num_heads)
+                       : (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                         vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
+            else
+                OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                                     vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
+            OP(VIT_OP_OUT_PROJ, vh_launch_linear_mx_resid_norm(s, ctx->x, l8[4], l8s[4], ctx->attn, as_, lw[5], ctx->x, rows, E, E,
+                                                               ctx->y, ys, ctx->stats));
+            OP(VIT_OP_FC1, vh_launch_linear_mx_norm(s, ctx->hid, hs, 1, l8[8], l8s[8], ctx->y, ys, ctx->stats, cs_f1, bf_f1, c->eps,
+                                                    rows, E, F, 1));
+            if (l == c->depth - 1)   /* nothing reads the operand behind the last layer: the final LayerNorm takes the fp32 rows */
+                OP(VIT_OP_FC2, vh_launch_linear_mx(s, ctx->x, NULL, l8[10], l8s[10], ctx->hid, hs, lw[11], rows, F, E, 0, ctx->x));
+            else
+                OP(VIT_OP_FC2, vh_launch_linear_mx_resid_norm(s, ctx->x, l8[10], l8s[10], ctx->hid, hs, lw[11], ctx->x, rows, F, E,
+                                                              ctx->y, ys, ctx->stats));
+            continue;
+        }
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[0], lw[1], ctx->y, ys, rows, E, E, c->eps));
         /* attention on fp16-rounded operands.  head_dim 64 / T <= 208: the projection's epilogue rounds Q|K|V to fp16
          * planes and the attention kernel writes the MX tensor; other shapes: fp32 out (into the idle MLP buffer),
@@ -690,6 +889,34 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
          * kernel as the fp32 path with one product per block (gemm_p3.hip, NPL = 1) */
         float **lw = w + 4 + 12 * l;
         void **lw16 = ctx->w16 + 4 + 12 * l;
+        if (fold) {
+            /* LayerNorms folded (csrc/norm_fold.h): ctx->y = bf16(x) planes and ctx->stats come from the patch embedding or the
+             * previous layer's fc2; QKV and fc1 apply the row terms in their epilogues; out-proj and fc2 refresh both */
+            const float *cs_in = ctx->fold_cs[4 + 12 * l + 2], *bf_in = ctx->fold_b[4 + 12 * l + 2];
+            const float *cs_f1 = ctx->fold_cs[4 + 12 * l + 8], *bf_f1 = ctx->fold_b[4 + 12 * l + 8];
+            const int planes_qkv = (E == 64 * c->num_heads && T <= 208) || (E == 80 * c->num_heads && T <= 272);
+            OP(VIT_OP_QKV, vh_launch_linear_planes_norm(s, ctx->qkv, planes_qkv ? 2 : 0, lw16[2], ctx->y, ctx->stats, cs_in, bf_in, c->eps,
+                                                        rows, E, 3 * E, 0));
+            if (E == 64 * c->num_heads && T <= 208)
+                OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16(s, ctx->qkv, ctx->attn, 1, n, T, E, c->num_heads));
+            else if (planes_qkv)
+                OP(VIT_OP_ATTENTION, (c->num_heads & 1) == 0
+                       ? vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, NULL, 1, n, T, E, c->num_heads)
+                       : (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                         vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
+            else
+                OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                                     vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
+            OP(VIT_OP_OUT_PROJ, vh_launch_linear_planes_resid_norm(s, ctx->x, lw16[4], ctx->attn, lw[5], ctx->x, rows, E, E, ctx->y, NULL,
+                                                                   ctx->stats));
+            OP(VIT_OP_FC1, vh_launch_linear_planes_norm(s, ctx->hid, 1, lw16[8], ctx->y, ctx->stats, cs_f1, bf_f1, c->eps, rows, E, F, 1));
+            if (l == c->depth - 1)   /* nothing reads the operand behind the last layer: the final LayerNorm takes the fp32 rows */
+                OP(VIT_OP_FC2, vh_launch_linear_planes(s, ctx->x, 0, lw16[10], ctx->hid, 1, lw[11], rows, F, E, 0, ctx->x));
+            else
+                OP(VIT_OP_FC2, vh_launch_linear_planes_resid_norm(s, ctx->x, lw16[10], ctx->hid, lw[11], ctx->x, rows, F, E, ctx->y, NULL,
+                                                                  ctx->stats));
+            continue;
+        }
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_planes(s, ctx->x, lw[0], lw[1], ctx->y, 1, rows, E, E, c->eps));
         if (E == 64 * c->num_heads && T <= 208) {   /* Q|K|V rounded to fp16 planes by the projection's epilogue */
             OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 2, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));

@@ -46,6 +46,10 @@ EXPORTS = [
     "vh_launch_attention_planes_f16", "vh_launch_linear_mx_planes_f16", "vh_launch_attention_planes_f16_mx",
     "vh_launch_attention_planes_f16_hd80", "vh_launch_attention_planes_f16_hd80_operand",
     "vh_launch_gather_rows", "vit_hip_set_last_layer_cls_only",
+    "vh_launch_conv_weight_planes_parts", "vh_launch_patch_embed_planes3",
+    "vh_launch_fold_gamma", "vh_launch_fold_bias", "vh_launch_colsum_operand", "vh_launch_patch_embed_planes_norm",
+    "vh_launch_linear_planes_norm", "vh_launch_linear_planes_resid_norm", "vh_launch_linear_mx_norm",
+    "vh_launch_linear_mx_resid_norm", "vit_hip_ln_fold",
     "vh_set_device", "vit_hip_create_multi", "vit_hip_forward_multi", "vit_hip_destroy_multi", "vit_hip_multi_devices",
     "vit_hip_multi_ctx", "vit_shard_range", "vit_shard_run", "vit_shard_run_timed", "vit_hip_multi_last_enqueue_ms",
     "vit_hip_forward_device_multi", "vit_hip_device", "vh_set_error",
@@ -184,6 +188,17 @@ def lib() -> C.CDLL:
     L.vh_launch_layer_norm_mx.argtypes = [voidp] + [voidp] * 5 + [i, i, C.c_long, C.c_double]
     L.vh_launch_linear_mx.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, voidp, voidp, i, i, i, i, voidp]
     L.vh_launch_linear_planes.argtypes = [voidp, voidp, i, voidp, voidp, i, voidp, i, i, i, i, voidp]
+    L.vh_launch_conv_weight_planes_parts.argtypes = [voidp, voidp, voidp, i, i, i, i]
+    L.vh_launch_patch_embed_planes3.argtypes = [voidp] + [voidp] * 6 + [i] * 5 + [voidp, sz]
+    L.vh_launch_fold_gamma.argtypes = [voidp, voidp, voidp, voidp, i, i]
+    L.vh_launch_fold_bias.argtypes = [voidp, voidp, voidp, voidp, voidp, i, i]
+    L.vh_launch_colsum_operand.argtypes = [voidp, voidp, voidp, voidp, i, i]
+    L.vh_launch_patch_embed_planes_norm.argtypes = [voidp] + [voidp] * 6 + [i] * 5 + [voidp, sz, voidp, voidp, voidp]
+    L.vh_launch_linear_planes_norm.argtypes = [voidp, voidp, i, voidp, voidp, voidp, voidp, voidp, C.c_double, i, i, i, i]
+    L.vh_launch_linear_planes_resid_norm.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, i, i, i, voidp, voidp, voidp]
+    L.vh_launch_linear_mx_norm.argtypes = [voidp, voidp, voidp, i, voidp, voidp, voidp, voidp, voidp, voidp, voidp, C.c_double, i, i, i, i]
+    L.vh_launch_linear_mx_resid_norm.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, voidp, voidp, i, i, i, voidp, voidp, voidp]
+    L.vit_hip_ln_fold.argtypes = [voidp]
     L.vit_config_preset.argtypes = [C.POINTER(VitConfig), C.c_char_p]
     L.vit_config_tokens.argtypes = [C.POINTER(VitConfig)]
     L.vit_config_num_tensors.argtypes = [C.POINTER(VitConfig)]
