@@ -32,9 +32,13 @@ def _ln_rows(x, gamma, beta, eps=EPS):
 def _folded_reference(x_oper, stats_rows, w_oper, colsum, bias_f, K, eps=EPS):
     """float64 evaluation of what the consuming kernel computes: operands as rounded, row terms from the fp32 partials"""
     s = stats_rows.astype(np.float32)
-    tot = s[0].copy()
-    for g in range(1, s.shape[0]):     # fixed order, fp32, as row_norm_terms
-        tot = tot + s[g]
+    lane = []                          # fixed order, fp32, as row_norm_terms: lane q adds partials q, q+4, q+8, q+12 ...
+    for q in range(4):
+        acc = np.zeros_like(s[0])
+        for g in range(q, s.shape[0], 4):
+            acc = acc + s[g]
+        lane.append(acc)
+    tot = (lane[0] + lane[1]) + (lane[2] + lane[3])     # ... and two shuffles add the four lane sums
     mean = tot[:, 0] / np.float32(K)
     var = tot[:, 1] / np.float32(K) - mean * mean
     rstd = (np.float32(1.0) / np.sqrt((var.astype(np.float64) + eps).astype(np.float32))).astype(np.float64)

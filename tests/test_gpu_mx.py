@@ -188,3 +188,28 @@ def test_attention_writing_mx_equals_attention_then_the_row_quantiser(pkg, devic
     assert np.array_equal(_bytes(d_s1, rows * E // 32), _bytes(d_s2, rows * E // 32))
     assert np.array_equal(_bytes(d_v1, rows * E), _bytes(d_v2, rows * E))
     assert pkg.lib().vh_launch_attention_planes_f16_mx(None, d_qh.ptr, d_v2.ptr, None, n_images, tokens, E, H) != 0
+
+
+def test_fc1_gelu_of_the_fp8_mode_holds_its_error_bound_for_every_x(pkg, device):
+    """The format-matched GELU of the fp8 mode's fc1 epilogue (gelu_lowp2<1>, csrc/gemm_common.h) through the MX GEMM with an
+    identity weight: every row holds one value v = +-(1 + m/8) 2^e repeated (exactly representable as block-scaled e4m3, the
+    product with 1.0 exact), e from -4 to 6: the dequantised output against erf-GELU (ViT_seq.c:283-287) within the stated
+    absolute 1.1e-4 plus one e4m3 rounding of the result, and the negative tail exactly zero -- the clamp of the polynomial's
+    argument used to leave -0.5 |x| erfc(3), -5.5e-4 at x = -50, which an all-negative block quantised as signal."""
+    from math import erf
+    vals = np.array([sgn * (1.0 + m / 8.0) * 2.0 ** e for sgn in (1.0, -1.0) for e in range(-4, 7) for m in range(8)], np.float32)
+    M, K = len(vals), 256
+    x = np.repeat(vals[:, None], K, axis=1)
+    w = np.eye(K, dtype=np.float32)
+    d_xv, d_xs = _quantize_gpu(pkg, x)
+    d_wv, d_ws = _quantize_gpu(pkg, w)
+    d_b = _dev(pkg, np.zeros(K, np.float32))
+    d_ov, d_os = pkg.DeviceBuffer(M * K // 4 + 4), pkg.DeviceBuffer(M * K // 128 + 4)
+    _launch(pkg, "vh_launch_linear_mx", None, d_ov.ptr, d_os.ptr, d_wv.ptr, d_ws.ptr, d_xv.ptr, d_xs.ptr, d_b.ptr, M, K, K, 1, None)
+    got = mx_ref.dequantize(_bytes(d_ov, M * K).reshape(K // 128, M, 128), _bytes(d_os, M * K // 32).reshape(K // 128, 4, M))[:, 0].astype(np.float64)
+    v64 = vals.astype(np.float64)
+    want = 0.5 * v64 * (1.0 + np.vectorize(erf)(v64 / np.sqrt(2.0)))
+    err = np.abs(got - want)
+    bound = 1.1e-4 + 2.0 ** -4 * np.abs(want)
+    assert (err <= bound).all(), f"v = {vals[np.argmax(err - bound)]}"
+    assert np.abs(got[vals <= -8.0]).max() == 0.0

@@ -153,6 +153,31 @@ def test_linear_p3_small_tiles_only_equal_big_tiles(pkg, device, oracle):
     assert np.array_equal(d_big.to_numpy((M, N))[:M2], d_o2.to_numpy((M2, N)))
 
 
+def test_linear_p3_narrow_tiles_of_small_batches_equal_the_128_tiles(pkg, device, oracle):
+    """Batch 64 (12 608 rows) of the N = 768 projections: 594 tiles of 128x128 on 256 CUs load the chip unevenly (two on
+    some CUs, three on others), so launch_p3_small takes 128x64 tiles there.  The same rows as the first half of a problem
+    twice as long -- 1182 tiles of 128x128, more than four per CU, so the wide tile -- come out bit for bit the same:
+    every tile shape computes the same k order."""
+    M, K, N = 12608, 768, 768
+    x = oracle.synth_fill(2 * M * K, 530, 1.0, 0.1)
+    w = oracle.synth_fill(N * K, 531, 0.04, 0.0)
+    b = oracle.synth_fill(N, 532, 0.1, 0.0)
+    r = oracle.synth_fill(2 * M * N, 533, 1.0, 0.0)
+    d_x, d_w, d_b = _dev(pkg, x), _dev(pkg, w), _dev(pkg, b)
+    d_w3, d_x3, d_x3h = _planes_buf(pkg, N, K), _planes_buf(pkg, 2 * M, K), _planes_buf(pkg, M, K)
+    _launch(pkg, "vh_launch_split3_planes", None, d_w.ptr, d_w3.ptr, N, K)
+    _launch(pkg, "vh_launch_split3_rows", None, d_x.ptr, d_x3.ptr, 2 * M, K)
+    _launch(pkg, "vh_launch_split3_rows", None, d_x.ptr, d_x3h.ptr, M, K)
+    d_long, d_half = _dev(pkg, r), _dev(pkg, r[:M * N])
+    _launch(pkg, "vh_launch_linear_p3", None, d_long.ptr, 0, d_w3.ptr, d_x3.ptr, d_b.ptr, 2 * M, K, N, 0, d_long.ptr)
+    _launch(pkg, "vh_launch_linear_p3", None, d_half.ptr, 0, d_w3.ptr, d_x3h.ptr, d_b.ptr, M, K, N, 0, d_half.ptr)
+    got = d_half.to_numpy((M, N))
+    assert np.array_equal(got, d_long.to_numpy((2 * M, N))[:M])
+    rows = _sample_rows(M, extra=(128, 6400))
+    want = r.reshape(2 * M, N)[rows] + oracle.linear(x.reshape(2 * M, K)[rows], w, b, N)
+    assert np.abs(got[rows] - want).max() <= OP_TOL
+
+
 @pytest.mark.parametrize("rows", [1, 5, 197, 1000])
 def test_layer_norm_p3_equals_layer_norm_split(pkg, device, oracle, weights, rows):
     x = oracle.synth_fill(rows * 768, 11 + rows, 3.0, 0.5).reshape(rows, 768)
@@ -545,3 +570,28 @@ def test_patch_embed_on_three_part_planes_vs_oracle_and_the_in_loop_split(pkg, d
     _launch(pkg, "vh_launch_patch_embed_ws", None, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d_tok2.ptr, n, 3, 224, P, E,
             d_ws2.ptr, ws2)
     assert np.array_equal(got, d_tok2.to_numpy((n, T, E)))
+
+
+def test_fc1_gelu_of_the_reduced_modes_holds_its_error_bound_for_every_x(pkg, device, oracle):
+    """The format-matched GELU of the bf16 mode's fc1 epilogue (gelu_lowp2<0>, csrc/gemm_common.h) through the GEMM with an
+    identity weight: outputs for x from -100 to 100 against erf-GELU (ViT_seq.c:283-287) -- within the stated absolute
+    1.8e-5 plus one bf16 rounding of the result EVERYWHERE, also far outside the fitted range (the clamp of the
+    polynomial's argument used to leave -0.5 |x| erfc(3.5): the error grew linearly with |x|)."""
+    from math import erf
+    M, K = 512, 128
+    xs = np.concatenate([np.linspace(-100.0, 100.0, 40001), np.linspace(-6.0, 6.0, 24000), [0.0] * 1535]).astype(np.float32)
+    xs = _bf16_rne(xs).reshape(M, K)                     # exactly representable operands: the product with 1.0 is exact
+    w = np.eye(K, dtype=np.float32)
+    d_x, d_w, d_b = _dev(pkg, xs), _dev(pkg, w), _dev(pkg, np.zeros(K, np.float32))
+    d_x1, d_w1, d_o1 = pkg.DeviceBuffer(M * K // 2), pkg.DeviceBuffer(K * K // 2), pkg.DeviceBuffer(M * K // 2)
+    _launch(pkg, "vh_launch_split_rows", None, d_x.ptr, d_x1.ptr, M, K, 1)
+    _launch(pkg, "vh_launch_split_rows", None, d_w.ptr, d_w1.ptr, K, K, 1)
+    _launch(pkg, "vh_launch_linear_planes", None, d_o1.ptr, 1, d_w1.ptr, d_x1.ptr, 1, d_b.ptr, M, K, K, 1, None)
+    got = _planes1_to_f32(d_o1, M, K).astype(np.float64)
+    x64 = xs.astype(np.float64)
+    want = 0.5 * x64 * (1.0 + np.vectorize(erf)(x64 / np.sqrt(2.0)))
+    err = np.abs(got - want)
+    bound = 1.8e-5 + 2.0 ** -8 * np.abs(want)
+    worst = np.unravel_index(np.argmax(err - bound), err.shape)
+    assert (err <= bound).all(), f"x = {xs[worst]}: got {got[worst]}, want {want[worst]}"
+    assert np.abs(got[xs <= -8.0]).max() <= 1e-6          # the negative tail is zero, not -0.5 |x| erfc(3.5)

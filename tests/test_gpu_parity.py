@@ -602,6 +602,22 @@ def test_c_driver_over_files_matches_reference_flow(pkg, device, weights, tmp_pa
     assert r4.returncode == 0 and "no weight files read" in r4.stdout, r4.stdout[-400:] + r4.stderr[-400:]
     first = (tmp_path / "Data" / "opencl_result.txt").read_text()
     assert (tmp_path / "Data" / "planes_result_1.txt").read_text() == first == (tmp_path / "Data" / "planes_result_2.txt").read_text()
+    assert not (tmp_path / "b16.planes.tmp").exists()            # written under a temporary name, renamed when complete
+    # a planes file that does not load (here: truncated) or that holds another precision than $VIT_HIP_PRECISION asks for is
+    # rebuilt from the weight files and rewritten, with a message -- never silently used, never a dead end
+    shutil.move(str(tmp_path / "Network_gone"), str(tmp_path / "Network"))
+    size = (tmp_path / "b16.planes").stat().st_size
+    with open(tmp_path / "b16.planes", "r+b") as f:
+        f.truncate(size // 2)
+    r5 = subprocess.run([str(exe), "./Data/input-100.bin", "./Network", "./Data/planes_result_3.txt", "./b16.planes"], cwd=tmp_path,
+                        capture_output=True, text=True, timeout=300)
+    assert r5.returncode == 0 and "rebuilding it from ./Network" in r5.stderr and (tmp_path / "b16.planes").stat().st_size == size, \
+        r5.stdout[-400:] + r5.stderr[-400:]
+    assert (tmp_path / "Data" / "planes_result_3.txt").read_text() == first
+    r6 = subprocess.run([str(exe), "./Data/input-100.bin", "./Network", "./Data/planes_result_4.txt", "./b16.planes"], cwd=tmp_path,
+                        capture_output=True, text=True, timeout=300, env=dict(os.environ, VIT_HIP_PRECISION="bf16"))
+    assert r6.returncode == 0 and "asks for 1" in r6.stderr and (tmp_path / "b16.planes").stat().st_size < size, \
+        r6.stdout[-400:] + r6.stderr[-400:]
     (tmp_path / "b16.planes").unlink()
     gold = np.load(root / "tests" / "golden" / "b16_full_rounded.npz")
     lines = (tmp_path / "Data" / "opencl_result.txt").read_text().splitlines()

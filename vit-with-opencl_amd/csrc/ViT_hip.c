@@ -422,7 +422,7 @@ static int want_ln_fold(const vit_config *cfg, int precision)
         return 0;
     if (env && env[0] == '0')
         return 0;
-    return cfg->embed_dim % 128 == 0 && (long)cfg->embed_dim / 128 <= 64;
+    return cfg->embed_dim % 128 == 0 && cfg->embed_dim / 128 <= 16;   /* row_norm_terms: at most 16 partial sums per row */
 }
 
 /* Argument checks shared by both ways of making a context, and the empty context itself. */

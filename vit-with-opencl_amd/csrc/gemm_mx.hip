@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
     if (NORM) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            row_norm_terms(p.stats, p.K >> 7, p.a_rows, (int)arow[i], p.K, p.eps, n_rstd[i], n_shift[i]);
+            row_norm_terms(p.stats, p.K >> 7, p.a_rows, (int)arow[i], j4, p.K, p.eps, n_rstd[i], n_shift[i]);
     }
 
     /* a fragment = two 16-byte halves (kept apart until the MFMA call) and the lane's scale byte */
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
 
     /* Epilogue: fragment pair (2s, 2s+1) of row block i = 8 consecutive columns n0 + 32s + 8 j4 .. +7 of one row.
      * Fragment pairs outermost: the folded LayerNorm's column terms are loaded once and serve both row blocks. */
-    float psum[2] = {0.0f, 0.0f}, psq[2] = {0.0f, 0.0f};   /* OPER: this lane's share of a row's (sum, sum of squares) over 128 columns */
+    /* OPER: this lane's share of a row's (sum, sum of squares) over 128 columns, even and odd elements apart (packed adds / fmas) */
+    f32x2 psum[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, psq[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
     for (int s = 0; s < JT / 2; ++s) {
         const int col = n0 + 32 * s + 8 * j4;
@@ -289,24 +290,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
                 }
                 if (OPER) {
                     /* the same eight values as the next projection's MX operand, and their share of the row's statistics
-                     * (fixed order: columns ascending per lane, then the four lanes of the row, per 128 columns) */
+                     * (fixed order: even and odd columns ascending per lane, their two sums, then the four lanes of the row, per 128 columns) */
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = e < 4 ? lo[e] : hi[e - 4];
-                        psum[i] += v;
-                        psq[i] += v * v;
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2 v = e < 2 ? f32x2{lo[2 * e], lo[2 * e + 1]} : f32x2{hi[2 * e - 4], hi[2 * e - 3]};
+                        psum[i] = psum[i] + v;
+                        psq[i] = __builtin_elementwise_fma(v, v, psq[i]);
                     }
                     mx_store_block8(lo, hi, static_cast<char *>(p.oper), static_cast<unsigned char *>(p.oper_scales), p.a_rows, arow[i],
                                     n0 + 32 * s, j4, live);
                     if ((s & 3) == 3) {
-                        float su = psum[i], sq2 = psq[i];
+                        float su = psum[i][0] + psum[i][1], sq2 = psq[i][0] + psq[i][1];
                         su += __shfl_xor(su, 16);
                         sq2 += __shfl_xor(sq2, 16);
                         su += __shfl_xor(su, 32);
                         sq2 += __shfl_xor(sq2, 32);
                         if (j4 == 0 && live)
                             *reinterpret_cast<f32x2 *>(p.stats_out + ((size_t)((n0 >> 7) + (s >> 2)) * p.a_rows + row) * 2) = f32x2{su, sq2};
-                        psum[i] = psq[i] = 0.0f;
+                        psum[i] = psq[i] = f32x2{0.0f, 0.0f};
                     }
                 }
             }
@@ -453,6 +454,8 @@ extern "C" int vh_launch_linear_mx_norm(vh_stream_t s, void *output, void *outpu
         return vh_fail(1, "vh_launch_linear_mx_norm: needs colA %% 256 == 0 and colB %% 128 == 0 (%d,%d,%d)", rowA, colA, colB);
     if (output_kind < 0 || output_kind > 2 || (doGelu && output_kind != 1))
         return vh_fail(1, "vh_launch_linear_mx_norm: unsupported epilogue combination");
+    if (colA > 16 * 128)
+        return vh_fail(1, "vh_launch_linear_mx_norm: colA=%d: at most 16 partial sums per row (colA <= 2048)", colA);
     if ((((uintptr_t)output | (uintptr_t)weight_values | (uintptr_t)input_values | (uintptr_t)colsum | (uintptr_t)bias_folded |
           (uintptr_t)weight_scales) & 15) != 0 || ((uintptr_t)row_stats & 7) != 0)
         return vh_fail(1, "vh_launch_linear_mx_norm: pointers must be 16-byte aligned (row_stats: 8)");

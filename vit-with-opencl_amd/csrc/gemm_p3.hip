@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
     if (NORM) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            row_norm_terms(p.stats, p.K >> 7, p.a_rows, min(m0 + 32 * wave + 16 * i + l15, p.row_end - 1), p.K, p.eps, n_rstd[i], n_shift[i]);
+            row_norm_terms(p.stats, p.K >> 7, p.a_rows, min(m0 + 32 * wave + 16 * i + l15, p.row_end - 1), q, p.K, p.eps, n_rstd[i], n_shift[i]);
     }
 
     frag_t a0[KG][2][NPL], a1[KG][2][NPL], w[RING][NPL];
@@ -292,7 +292,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
             posrow_[i] = p.pos + (size_t)(1 + pp) * p.N;
         }
     }
-    float psum[2] = {0.0f, 0.0f}, psq[2] = {0.0f, 0.0f};   /* OPER: this lane's share of a row's (sum, sum of squares) over 128 columns */
+    /* OPER: this lane's share of a row's (sum, sum of squares) over 128 columns, even and odd elements apart (packed adds / fmas) */
+    f32x2 psum[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, psq[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
     /* fragment pair s of row block i; nb = the folded-LayerNorm column terms (colsum lo/hi, folded bias lo/hi) */
     auto emit = [&](int i, int s, const f32x4 (&nb)[4]) {
         const int row = rows_[i];
@@ -346,13 +347,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
         }
         if (OPER) {
             /* the same eight values as the next projection's operand, and their share of the row's statistics (of the
-             * fp32 values, as layer_norm_seq ViT_seq.c:124-131 sums them; fixed order: columns ascending per lane, then
-             * the four lanes of the row, per 128 columns -- whatever the tile, the same sums) */
+             * fp32 values, as layer_norm_seq ViT_seq.c:124-131 sums them; fixed order: even and odd columns ascending per
+             * lane, their two sums, then the four lanes of the row, per 128 columns -- whatever the tile, the same sums) */
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = e < 4 ? lo[e] : hi[e - 4];
-                psum[i] += v;
-                psq[i] += v * v;
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 v = e < 2 ? f32x2{lo[2 * e], lo[2 * e + 1]} : f32x2{hi[2 * e - 4], hi[2 * e - 3]};
+                psum[i] = psum[i] + v;
+                psq[i] = __builtin_elementwise_fma(v, v, psq[i]);
             }
             if (OUTK == OUT_F32_OPER) {
                 frag_t part;
@@ -366,27 +367,48 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
                                 n0 + 32 * s, q, true);
             }
             if ((s & 3) == 3) {
-                float su = psum[i], sq2 = psq[i];
+                float su = psum[i][0] + psum[i][1], sq2 = psq[i][0] + psq[i][1];
                 su += __shfl_xor(su, 16);
                 sq2 += __shfl_xor(sq2, 16);
                 su += __shfl_xor(su, 32);
                 sq2 += __shfl_xor(sq2, 32);
                 if (q == 0)
                     *reinterpret_cast<f32x2 *>(p.stats_out + ((size_t)((n0 >> 7) + (s >> 2)) * p.c_rows + orow_[i]) * 2) = f32x2{su, sq2};
-                psum[i] = psq[i] = 0.0f;
+                psum[i] = psq[i] = f32x2{0.0f, 0.0f};
             }
         }
     };
-    if (NORM) {   /* column terms loaded once per fragment pair, shared by the two row blocks */
-#pragma unroll
-        for (int s = 0; s < JT / 2; ++s) {
+    if (NORM) {   /* column terms read once per fragment pair, shared by the two row blocks */
+        auto column_terms = [&](int s, f32x4 (&nb)[4]) {
             const int c_lo = frag_col(2 * s), c_hi = frag_col(2 * s + 1);
-            const f32x4 nb[4] = {*reinterpret_cast<const f32x4 *>(ncol + c_lo), *reinterpret_cast<const f32x4 *>(ncol + c_hi),
-                                 *reinterpret_cast<const f32x4 *>(ncol + BN + c_lo), *reinterpret_cast<const f32x4 *>(ncol + BN + c_hi)};
+            nb[0] = *reinterpret_cast<const f32x4 *>(ncol + c_lo);
+            nb[1] = *reinterpret_cast<const f32x4 *>(ncol + c_hi);
+            nb[2] = *reinterpret_cast<const f32x4 *>(ncol + BN + c_lo);
+            nb[3] = *reinterpret_cast<const f32x4 *>(ncol + BN + c_hi);
+        };
+        if (m0 + BM <= p.row_end) {   /* every tile but the last row of tiles: straight-line code, no per-lane conditions --
+                                       * with a condition around every (pair, row block) the GELU chains of different pairs
+                                       * cannot be interleaved and the epilogue ran at the latency of one chain */
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (rows_[i] < p.row_end)
+            for (int s = 0; s < JT / 2; ++s) {
+                f32x4 nb[4];
+                column_terms(s, nb);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
                     emit(i, s, nb);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (rows_[i] >= p.row_end)
+                    continue;
+#pragma unroll
+                for (int s = 0; s < JT / 2; ++s) {
+                    f32x4 nb[4];
+                    column_terms(s, nb);
+                    emit(i, s, nb);
+                }
+            }
         }
     } else {
         const f32x4 none[4] = {};
@@ -421,6 +443,26 @@ int launch_p3_tile(hipStream_t st, P3Params p)
  * 128x128 tile alone: at equal work it is within 3 % of the big tile, and it quantises four times finer
  * (batch 64: 5495 against 4947 images/s).  Every tile computes the same k order: results do not depend on
  * the choice. */
+/* Small problems on 128x128 tiles (batch 64: 12 608 rows) leave the chip unevenly loaded when N is small: the N = 768
+ * projections are 594 tiles on 256 CUs -- two on some CUs, three on others, and the launch takes as long as three.  When
+ * a CU gets fewer than four such tiles and halving the tiles shortens the busiest CU's queue, 128x64 tiles (4 waves of
+ * 32x64; twice as many, half the size) level it: 4.64 per CU, busiest 5 = 2.5 tile times instead of 3.
+ * Same k order: the same bits.  $VIT_HIP_NARROW_TILES=0 keeps 128x128 (the A/B of profiles/r04_bench_batch64*). */
+template <int EPI, int OUTK, int NPL>
+int launch_p3_small(hipStream_t st, const P3Params &p)
+{
+    if constexpr (OUTK != OUT_F32_OPER && OUTK != OUT_F32_OPER_MX) {
+        static const bool narrow_ok = [] { const char *e = getenv("VIT_HIP_NARROW_TILES"); return !(e && e[0] == '0'); }();
+        const long cus = vh_device_cus(vh_current_device());
+        const long tiles = (long)((p.row_end - p.row_begin + 127) / 128) * (p.N / 128);
+        /* makespan in tile times: the busiest CU's tiles; a 128x64 tile counts half, plus 5 % for its lower intensity */
+        const long busiest = (tiles + cus - 1) / cus, busiest_narrow = (2 * tiles + cus - 1) / cus;
+        if (narrow_ok && p.N % 128 == 0 && tiles < 4 * cus && 105 * busiest_narrow < 200 * busiest)
+            return launch_p3_tile<4, 64, EPI, OUTK, NPL>(st, p);
+    }
+    return launch_p3_tile<4, 128, EPI, OUTK, NPL>(st, p);
+}
+
 template <int EPI, int OUTK, int NPL>
 int launch_p3(hipStream_t st, const P3Params &p, int small_only)
 {
@@ -435,7 +477,7 @@ int launch_p3(hipStream_t st, const P3Params &p, int small_only)
     if ((EPI == EPI_RESID || EPI == EPI_PATCH) && NPL == 1 && p.N % 256 == 0 && tiles >= num_cus)
         return launch_p3_tile<4, 256, EPI, OUTK, NPL>(st, p);
     if (p.N % 256 != 0 || small_only || 2 * tiles < 5 * (long)num_cus)
-        return launch_p3_tile<4, 128, EPI, OUTK, NPL>(st, p);
+        return launch_p3_small<EPI, OUTK, NPL>(st, p);
     const long full = tiles / num_cus, rem = tiles % num_cus;
     const int rows_big = (int)(full * num_cus / ntiles) * 256;
     auto big_tiles = [&](const P3Params &q) { return launch_p3_tile<8, 256, EPI, OUTK, NPL>(st, q); };
@@ -606,6 +648,8 @@ extern "C" int vh_launch_linear_planes_norm(vh_stream_t s, void *output, int out
         return vh_fail(1, "vh_launch_linear_planes_norm: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", 64 * P1_KG, rowA, colA, colB);
     if (output_planes < 0 || output_planes > 2 || (output_planes == 2 && doGelu) || (output_planes == 0 && doGelu))
         return vh_fail(1, "vh_launch_linear_planes_norm: unsupported epilogue combination");
+    if (colA > 16 * 128)
+        return vh_fail(1, "vh_launch_linear_planes_norm: colA=%d: at most 16 partial sums per row (colA <= 2048)", colA);
     if ((((uintptr_t)output | (uintptr_t)weight_planes | (uintptr_t)input_planes | (uintptr_t)colsum | (uintptr_t)bias_folded) & 15) != 0 ||
         ((uintptr_t)row_stats & 7) != 0)
         return vh_fail(1, "vh_launch_linear_planes_norm: pointers must be 16-byte aligned (row_stats: 8)");

@@ -27,16 +27,25 @@
 #include "vit_kernels.h"
 #include "gemm_common.h"
 
-/* 1/std and -mean/std of row `row` from its producer's partial sums (groups = K / 128) */
-__device__ __forceinline__ void row_norm_terms(const float *stats, int groups, int rows, int row, int K, double eps, float &rstd,
+/* 1/std and -mean/std of row `row` from its producer's partial sums (groups = K / 128 <= 16).  Called by all four lanes
+ * (q = lane >> 4) that hold the row in the GEMM epilogue's layout: lane q takes partials q, q + 4, q + 8, q + 12 (four
+ * independent loads, issued together -- a loop over the groups with one load per trip cost a round trip to L2 per trip in
+ * every tile's prologue), two shuffles add the four lane sums: ((s0 + s1) + (s2 + s3)), the same bits in every lane. */
+__device__ __forceinline__ void row_norm_terms(const float *stats, int groups, int rows, int row, int q, int K, double eps, float &rstd,
                                                float &shift)
 {
     float sum = 0.0f, sq = 0.0f;
-    for (int g = 0; g < groups; ++g) {   /* fixed order */
-        const f32x2 t = *reinterpret_cast<const f32x2 *>(stats + ((size_t)g * rows + row) * 2);
-        sum += t[0];
-        sq += t[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = q + 4 * j;
+        const f32x2 t = *reinterpret_cast<const f32x2 *>(stats + ((size_t)min(g, groups - 1) * rows + row) * 2);
+        sum += g < groups ? t[0] : 0.0f;
+        sq += g < groups ? t[1] : 0.0f;
     }
+    sum += __shfl_xor(sum, 16);
+    sq += __shfl_xor(sq, 16);
+    sum += __shfl_xor(sum, 32);
+    sq += __shfl_xor(sq, 32);
     const float mean = sum / (float)K;
     const float var = sq / (float)K - mean * mean;
     rstd = 1.0f / sqrtf((float)((double)var + eps));
