@@ -156,6 +156,70 @@ def committed_traffic(root: Path):
     return (None if stale else rec["traffic_bytes_per_launch"]), src, stale
 
 
+FC1_KERNELS = ("gemm_p3_kernel<8, 256, 1, 1, 3>", "gemm_p3_kernel<4, 128, 1, 1, 3>")   # EPI_GELU, OUT_PLANES, three parts: fc1 only
+
+
+def pmc_child(B: int) -> None:
+    """Child-process leg run UNDER rocprofv3 by measure_fc1_traffic: two forwards of the default fp32 path at batch B (the
+    counters do not depend on the pixel values: the image buffer is zero-filled).  No torch in this process."""
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    L = pkg.lib()
+    cfg = pkg.preset("vit_b_16")
+    model = pkg.ViTHip(cfg, pkg.synth_weights(cfg, 0), device=0, max_batch=B)
+    d_images = pkg.DeviceBuffer(B * cfg.in_chans * cfg.img_size * cfg.img_size)
+    pkg.binding.check(L.vh_memset(d_images.ptr, 0, B * cfg.in_chans * cfg.img_size * cfg.img_size * 4, None), "vh_memset")
+    d_logits = pkg.DeviceBuffer(B * cfg.num_classes)
+    for _ in range(2):
+        model.forward_device(d_images.ptr, B, d_logits.ptr, None, model.stream)
+    pkg.binding.check(L.vh_device_sync(), "sync")
+    model.close()
+
+
+def measure_fc1_traffic(B: int):
+    """HBM-side bytes per fc1 launch, measured in THIS run: two separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE --
+    they do not fit one pass, MI355X_MICROARCH.md) over a child process that runs the same forward, per-dispatch means
+    of the fc1 kernels (the 256x256-tile launch + its 128x128-tile launch) added, corrected as the guide prescribes:
+    counters are KiB, and on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads.  -> (bytes | None, note)"""
+    import csv
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VIT_HIP_NO_TORCH="1", TMPDIR="/tmp")
+    means = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = Path(td) / counter
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", str(out), "--", sys.executable,
+                   str(Path(__file__).resolve()), "--pmc-child", "--batch", str(B)]
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter}: timed out"
+            files = list(out.rglob("*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter}: exit {r.returncode}: {r.stderr[-200:]}"
+            per_kernel = {}
+            with open(files[0], newline="") as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    name = row["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+                    if name in FC1_KERNELS:
+                        per_kernel.setdefault(name, []).append(float(row["Counter_Value"]))
+            if FC1_KERNELS[0] not in per_kernel:
+                return None, f"no fc1 dispatch in the {counter} pass"
+            means[counter] = sum(sum(v) / len(v) for v in per_kernel.values())      # big launch + tail launch, mean per dispatch each
+    traffic = (2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0
+    return traffic, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes, child process, "
+                     f"{time.perf_counter() - t0:.0f} s), per-dispatch means of {' + '.join(FC1_KERNELS)}; "
+                     f"traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of wide reads; L2 memory side, "
+                     f"Infinity-Cache hits included); FETCH_SIZE {means['FETCH_SIZE']:.0f} KiB, WRITE_SIZE {means['WRITE_SIZE']:.0f} KiB")
+
+
 def spawn_ranks(n: int) -> int:
     """Start `n` ranks of this script under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) as a child
     process and wait for it.  Called before anything in this process has initialised the GPU; nothing is re-exec'd."""
@@ -275,11 +339,15 @@ def main() -> None:
     ap.add_argument("--no-in-library-multi", action="store_true", help="skip the in-library multi-GPU leg (child process)")
     ap.add_argument("--sustain-s", type=float, default=30.0,
                     help="seconds of the same step behind the timed region for the `sustained` leg (0 = skip)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 PMC passes (child process)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--in-library-multi-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--first-device", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.in_library_multi_child:
         return in_library_multi_child(args.in_library_multi_child, args.first_device, args.batch, args.steps)
+    if args.pmc_child:
+        return pmc_child(args.batch)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks as children of this process, which has
@@ -490,6 +558,7 @@ def main() -> None:
 
     def secondary(precision, label, peak_tf, peak_note):
         m2 = pkg.ViTHip(cfg, weights, device=device, max_batch=B, precision=precision)
+        folded2 = bool(L.vit_hip_ln_fold(m2.ctx))
         d_l2 = pkg.DeviceBuffer(B * NC)
         for _ in range(2):
             m2.forward_device(d_images.ptr, B, d_l2.ptr, d_probs.ptr, m2.stream)
@@ -516,6 +585,8 @@ def main() -> None:
                  "roofline": {"bound": "mfma", "kernel": "fc1 GEMM of this mode", "achieved": round(fc1_tf, 1), "peak": peak_tf,
                               "unit": "TFLOP/s", "frac": round(fc1_tf / peak_tf, 4), "peak_basis": peak_note, "traffic": None},
                  "end_to_end": e2e2,
+                 "layer_norms_folded": folded2,
+                 "launches_per_step": {k: cnt // 2 for k, (ms, cnt) in p2.items() if cnt},
                  "kernels_avg_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in p2.items() if cnt}}, l2)
 
     # Opt-in leg (never `value`): the last encoder layer's output projection and MLP evaluated for the class-token
@@ -623,6 +694,11 @@ def main() -> None:
                     not os.environ.get("VIT_HIP_GEMM_FP32", "s").startswith("n")
                 bytes_per = B * tokens * cfg.embed_dim * (4.0 + (6.0 if p3_ln else 4.0 if args.dtype in ("f32", "f32_fp16x2") else
                                                                  2.0 if args.dtype == "bf16" else 1.03125 if args.dtype == "fp8" else 1.0))
+                if cnt // PROF_STEPS == 1:
+                    # the reduced modes fold every LayerNorm but the final one into the projection behind it (csrc/norm_fold.h):
+                    # what is left is the final LayerNorm on the B class-token rows, fp32 in and out -- a launch-latency kernel
+                    bytes_per = B * cfg.embed_dim * 8.0
+                    entry["note"] = "final LayerNorm on the class-token rows only; the other 24 are folded into the QKV / fc1 projections"
                 entry["gbs"] = round(bytes_per / (avg_ms * 1e-3) / 1e9, 1)
                 entry["frac_hbm_peak"] = round(entry["gbs"] / PEAK_HBM_GBS, 4)
             kernels[name] = entry
@@ -655,7 +731,14 @@ def main() -> None:
         # of csrc/gemm_p3.hip; when the file has changed since, the figure is withheld and marked stale.
         traffic, traffic_src, traffic_stale = None, None, None
         if B == 512 and args.model == "vit_b_16" and p3:
-            traffic, traffic_src, traffic_stale = committed_traffic(ROOT)
+            if comm is None and not args.no_pmc and "VIT_HIP_P3" not in os.environ:
+                traffic, traffic_src = measure_fc1_traffic(B)      # live: PMC passes over a child process of this very run
+                traffic_stale = False if traffic is not None else None
+            if traffic is None:     # N > 1, --no-pmc, or the profiler could not run: the committed passes, tied to the kernel source
+                live_note = traffic_src
+                traffic, traffic_src, traffic_stale = committed_traffic(ROOT)
+                if live_note and traffic_src:
+                    traffic_src += f" [live measurement unavailable: {live_note}]"
         rows = B * tokens
         if p3:     # operands and result as three bf16 parts: 6 bytes per value
             alg_bytes = (rows * (cfg.embed_dim + cfg.mlp_hidden) + cfg.mlp_hidden * cfg.embed_dim) * 6
@@ -707,6 +790,7 @@ def main() -> None:
                                 "fp32 operands split exactly into 3 bf16 parts, 6 bf16 MFMAs per product, fp32 accumulate"),
             "model_tflops": round(total_flops * B * args.steps * world / elapsed / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(total_flops * B * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "layer_norms_folded": bool(L.vit_hip_ln_fold(model.ctx)),
             "roofline": roofline, "kernels": kernels,
             "kernels_note": f"per-operator averages from a separate pass of {PROF_STEPS} steps with every launch bracketed "
                             "by HIP events; the roofline kernel is bracketed inside the timed region",

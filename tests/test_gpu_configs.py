@@ -109,9 +109,11 @@ def test_vit_h14_full_depth_logits_of_every_precision_vs_port_golden(pkg, device
         assert np.isfinite(l16).all() and np.isfinite(l8).all()
         # bf16 mode, 32 layers: measured max |dlogit| 2.1e-2, relative L2 0.62 %; stated bound 5e-2 / 1.5 %
         assert e16 <= 5e-2 and r16 <= 1.5e-2 and _clear_top1(l16, want_l)
-        # fp8 mode (config 5's precision), 32 layers: measured relative L2 0.095-0.097 (max |dlogit| 0.31); stated bound
-        # 0.15 (round 2 asserted 0.25, and against this library's own fp32 path instead of the port)
-        assert r8 <= 0.15 and _clear_top1(l8, want_l)
+        # fp8 mode (config 5's precision), 32 layers: measured relative L2 0.093-0.097 (max |dlogit| 0.31).  The bound is
+        # 1.3 x what the independent error model predicts for this model (tools/quant_sensitivity.py, a PyTorch restatement
+        # with fake-quantised operands: 0.0924 with the LayerNorms folded, profiles/r04_quant_sensitivity.txt) = 0.12
+        # (round 3 asserted 0.15, set from the measurement itself; round 2 0.25 against this library's own fp32 path)
+        assert r8 <= 0.12 and _clear_top1(l8, want_l)
         assert abs(float(out["fp8"][1][i].sum()) - 1.0) < 1e-5
 
 

@@ -213,3 +213,36 @@ def test_fc1_gelu_of_the_fp8_mode_holds_its_error_bound_for_every_x(pkg, device)
     bound = 1.1e-4 + 2.0 ** -4 * np.abs(want)
     assert (err <= bound).all(), f"v = {vals[np.argmax(err - bound)]}"
     assert np.abs(got[vals <= -8.0]).max() == 0.0
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_reduced_modes_against_the_fp32_path_over_256_images(pkg, device, weights, precision):
+    """The reduced modes' error against an error MODEL rather than against last round's measurement: tools/quant_sensitivity.py
+    restates the forward pass in PyTorch with the modes' operand formats as fake-quantisers and predicts the relative L2
+    error of the class logits (profiles/r04_quant_sensitivity.txt: ViT-B/16, LayerNorms folded: block-scaled e4m3 on all
+    eight operand classes 0.0745, bf16 on all eight 0.0050; no single class carries more than a quarter of the squared
+    error, weights and activations contribute alike).  Over 256 images the library must stay within 1.3 x that
+    prediction, and its top-1 / top-5 decisions must agree with the fp32 path's as far as that much logit noise
+    allows on random-weight logits (top-2 margins of a fraction of the noise): measured here and printed."""
+    cfg = pkg.preset("vit_b_16")
+    n = 256
+    imgs = pkg.synth_images(cfg, 0, n)
+    m32 = pkg.ViTHip(cfg, weights, device=0, max_batch=64)
+    ref, _ = m32.forward(imgs)
+    m32.close()
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=64, precision=precision)
+    got, probs = m.forward(imgs)
+    m.close()
+    spread = np.linalg.norm(ref - ref.mean(axis=1, keepdims=True), axis=1)
+    rel = np.linalg.norm(got - ref, axis=1) / spread
+    top1 = float(np.mean(got.argmax(1) == ref.argmax(1)))
+    top5 = float(np.mean([len(set(np.argsort(a)[-5:]) & set(np.argsort(b)[-5:])) / 5 for a, b in zip(got, ref)]))
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 4 * np.abs(got - ref).max(axis=1)
+    print(f"\n{precision} vs fp32 path, {n} images: relative L2 mean {rel.mean():.4f} max {rel.max():.4f}; top-1 agreement {top1:.3f}, "
+          f"top-5 overlap {top5:.3f}; images whose fp32 top-2 margin exceeds 4x their logit error: {int(clear.sum())}")
+    model = {"bf16": 0.0050, "fp8": 0.0745}[precision]
+    assert np.isfinite(got).all() and np.abs(probs.sum(axis=1) - 1.0).max() < 1e-5
+    assert rel.mean() <= 1.3 * model and rel.max() <= 1.6 * model
+    assert (got.argmax(1) == ref.argmax(1))[clear].all()
+    assert top1 >= {"bf16": 0.95, "fp8": 0.70}[precision] and top5 >= {"bf16": 0.97, "fp8": 0.80}[precision]

@@ -153,31 +153,6 @@ def test_linear_p3_small_tiles_only_equal_big_tiles(pkg, device, oracle):
     assert np.array_equal(d_big.to_numpy((M, N))[:M2], d_o2.to_numpy((M2, N)))
 
 
-def test_linear_p3_narrow_tiles_of_small_batches_equal_the_128_tiles(pkg, device, oracle):
-    """Batch 64 (12 608 rows) of the N = 768 projections: 594 tiles of 128x128 on 256 CUs load the chip unevenly (two on
-    some CUs, three on others), so launch_p3_small takes 128x64 tiles there.  The same rows as the first half of a problem
-    twice as long -- 1182 tiles of 128x128, more than four per CU, so the wide tile -- come out bit for bit the same:
-    every tile shape computes the same k order."""
-    M, K, N = 12608, 768, 768
-    x = oracle.synth_fill(2 * M * K, 530, 1.0, 0.1)
-    w = oracle.synth_fill(N * K, 531, 0.04, 0.0)
-    b = oracle.synth_fill(N, 532, 0.1, 0.0)
-    r = oracle.synth_fill(2 * M * N, 533, 1.0, 0.0)
-    d_x, d_w, d_b = _dev(pkg, x), _dev(pkg, w), _dev(pkg, b)
-    d_w3, d_x3, d_x3h = _planes_buf(pkg, N, K), _planes_buf(pkg, 2 * M, K), _planes_buf(pkg, M, K)
-    _launch(pkg, "vh_launch_split3_planes", None, d_w.ptr, d_w3.ptr, N, K)
-    _launch(pkg, "vh_launch_split3_rows", None, d_x.ptr, d_x3.ptr, 2 * M, K)
-    _launch(pkg, "vh_launch_split3_rows", None, d_x.ptr, d_x3h.ptr, M, K)
-    d_long, d_half = _dev(pkg, r), _dev(pkg, r[:M * N])
-    _launch(pkg, "vh_launch_linear_p3", None, d_long.ptr, 0, d_w3.ptr, d_x3.ptr, d_b.ptr, 2 * M, K, N, 0, d_long.ptr)
-    _launch(pkg, "vh_launch_linear_p3", None, d_half.ptr, 0, d_w3.ptr, d_x3h.ptr, d_b.ptr, M, K, N, 0, d_half.ptr)
-    got = d_half.to_numpy((M, N))
-    assert np.array_equal(got, d_long.to_numpy((2 * M, N))[:M])
-    rows = _sample_rows(M, extra=(128, 6400))
-    want = r.reshape(2 * M, N)[rows] + oracle.linear(x.reshape(2 * M, K)[rows], w, b, N)
-    assert np.abs(got[rows] - want).max() <= OP_TOL
-
-
 @pytest.mark.parametrize("rows", [1, 5, 197, 1000])
 def test_layer_norm_p3_equals_layer_norm_split(pkg, device, oracle, weights, rows):
     x = oracle.synth_fill(rows * 768, 11 + rows, 3.0, 0.5).reshape(rows, 768)

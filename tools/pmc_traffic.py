@@ -31,8 +31,8 @@ def blocks(path):
 
 def main(path):
     b = blocks(path)
-    big = b[("gemm_p3_kernel<8, 256, 1, 1, 3, 0>", (SPLIT_ROW // 256) * (N // 256) * 512)]
-    tail = b[("gemm_p3_kernel<4, 128, 1, 1, 3, 0>", ((M - SPLIT_ROW) // 128) * (N // 128) * 256)]
+    big = b[("gemm_p3_kernel<8, 256, 1, 1, 3>", (SPLIT_ROW // 256) * (N // 256) * 512)]
+    tail = b[("gemm_p3_kernel<4, 128, 1, 1, 3>", ((M - SPLIT_ROW) // 128) * (N // 128) * 256)]
     fetch, write = big["FETCH_SIZE"] + tail["FETCH_SIZE"], big["WRITE_SIZE"] + tail["WRITE_SIZE"]
     alg = (M * (K + N) + N * K) * 6
     try:

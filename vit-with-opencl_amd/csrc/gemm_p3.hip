@@ -442,27 +442,8 @@ int launch_p3_tile(hipStream_t st, P3Params p)
  * has 0.6 to 2.3 rounds of big tiles per projection -- and the N = K = 768 output projection run on the
  * 128x128 tile alone: at equal work it is within 3 % of the big tile, and it quantises four times finer
  * (batch 64: 5495 against 4947 images/s).  Every tile computes the same k order: results do not depend on
- * the choice. */
-/* Small problems on 128x128 tiles (batch 64: 12 608 rows) leave the chip unevenly loaded when N is small: the N = 768
- * projections are 594 tiles on 256 CUs -- two on some CUs, three on others, and the launch takes as long as three.  When
- * a CU gets fewer than four such tiles and halving the tiles shortens the busiest CU's queue, 128x64 tiles (4 waves of
- * 32x64; twice as many, half the size) level it: 4.64 per CU, busiest 5 = 2.5 tile times instead of 3.
- * Same k order: the same bits.  $VIT_HIP_NARROW_TILES=0 keeps 128x128 (the A/B of profiles/r04_bench_batch64*). */
-template <int EPI, int OUTK, int NPL>
-int launch_p3_small(hipStream_t st, const P3Params &p)
-{
-    if constexpr (OUTK != OUT_F32_OPER && OUTK != OUT_F32_OPER_MX) {
-        static const bool narrow_ok = [] { const char *e = getenv("VIT_HIP_NARROW_TILES"); return !(e && e[0] == '0'); }();
-        const long cus = vh_device_cus(vh_current_device());
-        const long tiles = (long)((p.row_end - p.row_begin + 127) / 128) * (p.N / 128);
-        /* makespan in tile times: the busiest CU's tiles; a 128x64 tile counts half, plus 5 % for its lower intensity */
-        const long busiest = (tiles + cus - 1) / cus, busiest_narrow = (2 * tiles + cus - 1) / cus;
-        if (narrow_ok && p.N % 128 == 0 && tiles < 4 * cus && 105 * busiest_narrow < 200 * busiest)
-            return launch_p3_tile<4, 64, EPI, OUTK, NPL>(st, p);
-    }
-    return launch_p3_tile<4, 128, EPI, OUTK, NPL>(st, p);
-}
-
+ * the choice.  (Round 4 tried 128x64 tiles for batch 64's N = 768 projections -- 594 tiles of 128x128 sit two on some CUs
+ * and three on others -- and lost: twice the A re-reads per MFMA make that tile L2-bound; profiles/r04_bench_batch64_*.) */
 template <int EPI, int OUTK, int NPL>
 int launch_p3(hipStream_t st, const P3Params &p, int small_only)
 {
@@ -477,7 +458,7 @@ int launch_p3(hipStream_t st, const P3Params &p, int small_only)
     if ((EPI == EPI_RESID || EPI == EPI_PATCH) && NPL == 1 && p.N % 256 == 0 && tiles >= num_cus)
         return launch_p3_tile<4, 256, EPI, OUTK, NPL>(st, p);
     if (p.N % 256 != 0 || small_only || 2 * tiles < 5 * (long)num_cus)
-        return launch_p3_small<EPI, OUTK, NPL>(st, p);
+        return launch_p3_tile<4, 128, EPI, OUTK, NPL>(st, p);
     const long full = tiles / num_cus, rem = tiles % num_cus;
     const int rows_big = (int)(full * num_cus / ntiles) * 256;
     auto big_tiles = [&](const P3Params &q) { return launch_p3_tile<8, 256, EPI, OUTK, NPL>(st, q); };
