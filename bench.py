@@ -454,53 +454,6 @@ def main() -> None:
     if comm is not None:
         elapsed = comm.max_over_ranks(elapsed)
 
-    # Sustained load: the SAME step for >= 30 s of wall time behind the timed region.  `value` rests on a window of a
-    # second or two on a board that regulates power over milliseconds and temperature over tens of seconds; this leg
-    # says what the rate is once the board is warm.  Every rank runs the same number of steps (the count follows from
-    # the max-over-ranks time above), synchronised about once a second; fc1's per-launch time (HIP events, as in the
-    # timed region) is the clock proxy.  No reference counterpart (Main.c:51-57 times one shot).
-    sustained = None
-    if args.sustain_s > 0:
-        step_s = elapsed / args.steps
-        chunk = max(1, int(round(1.0 / step_s)))
-        n_chunks = max(2, int(np.ceil(args.sustain_s / (chunk * step_s))))
-        model.profile_select(["fc1_gemm"])
-        model.profile_enable(chunk)          # every read below rewinds the event pool
-        marks, fc1_marks = [], []
-        fence()
-        t0s = time.perf_counter()
-        for _ in range(n_chunks):
-            for _ in range(chunk):
-                step()
-            if use_rccl:
-                torch.cuda.synchronize()
-            pkg.binding.check(L.vh_device_sync(), "sync")
-            marks.append(time.perf_counter() - t0s)
-            ms_c, cnt_c = model.profile_read()["fc1_gemm"]
-            fc1_marks.append(ms_c / max(cnt_c, 1))
-        model.profile_enable(0)
-        model.profile_select(None)
-        total_s = marks[-1]
-
-        def window(lo_s, hi_s):
-            """chunks that END inside (lo_s, hi_s]: images/s per GPU and mean fc1 ms over them"""
-            idx = [k for k, t in enumerate(marks) if lo_s < t <= hi_s] or [len(marks) - 1]
-            t_begin = marks[idx[0] - 1] if idx[0] > 0 else 0.0
-            rate = len(idx) * chunk * B / (marks[idx[-1]] - t_begin)
-            return rate, float(np.mean([fc1_marks[k] for k in idx]))
-        first_rate, first_fc1 = window(0.0, 5.0)
-        last_rate, last_fc1 = window(total_s - 5.0, total_s)
-        if comm is not None:     # slowest rank decides, as for `value`
-            first_rate = B * chunk / comm.max_over_ranks(B * chunk / first_rate)
-            last_rate = B * chunk / comm.max_over_ranks(B * chunk / last_rate)
-        sustained = {"what": f"the same step repeated for {total_s:.1f} s behind the timed region ({chunk * n_chunks} steps, host "
-                             f"sync every {chunk}); whole-job images/sec over the first and the last 5 s, fc1 ms per launch "
-                             "(HIP events) as the clock proxy",
-                     "seconds": round(total_s, 2), "steps": chunk * n_chunks,
-                     "first_5s": {"value": round(world * first_rate, 1), "fc1_ms": round(first_fc1, 4)},
-                     "last_5s": {"value": round(world * last_rate, 1), "fc1_ms": round(last_fc1, 4)},
-                     "mean": round(world * B * chunk * n_chunks / total_s, 1), "unit": "images/sec"}
-
     # N > 1: rank 0 checks what the gather delivered.  Its own rows must be its own logits; for every other rank
     # it recomputes that rank's first and last images (global index r*B + i) ON THE SAME BATCH POSITIONS -- so the
     # same tiles and launches produce them -- and requires the gathered rows to equal them bit for bit.
@@ -560,14 +513,14 @@ def main() -> None:
         m2 = pkg.ViTHip(cfg, weights, device=device, max_batch=B, precision=precision)
         folded2 = bool(L.vit_hip_ln_fold(m2.ctx))
         d_l2 = pkg.DeviceBuffer(B * NC)
-        for _ in range(2):
+        for _ in range(3):
             m2.forward_device(d_images.ptr, B, d_l2.ptr, d_probs.ptr, m2.stream)
         pkg.binding.check(L.vh_device_sync(), "sync")
         t2 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(10):
             m2.forward_device(d_images.ptr, B, d_l2.ptr, d_probs.ptr, m2.stream)
         pkg.binding.check(L.vh_device_sync(), "sync")
-        dt2 = (time.perf_counter() - t2) / 5
+        dt2 = (time.perf_counter() - t2) / 10
         m2.profile_enable(2)
         for _ in range(2):
             m2.forward_device(d_images.ptr, B, d_l2.ptr, d_probs.ptr, m2.stream)
@@ -669,6 +622,54 @@ def main() -> None:
                    "images_per_sec_whole_call": round(n_di / min(walls), 1),
                    "argmax_equal_to_device_resident_path": bool((h_probs.argmax(1) == own[:n_di].argmax(1)).all())
                    if B >= n_di else None}
+
+    # Sustained load: the SAME step for >= 30 s of wall time behind the timed region (and behind the secondary legs, so
+    # that those stay comparable with earlier rounds' lines).  `value` rests on a window of a second or two on a board
+    # that regulates power over milliseconds and temperature over tens of seconds; this leg says what the rate is once
+    # the board is warm.  Every rank runs the same number of steps (the count follows from
+    # the max-over-ranks time above), synchronised about once a second; fc1's per-launch time (HIP events, as in the
+    # timed region) is the clock proxy.  No reference counterpart (Main.c:51-57 times one shot).
+    sustained = None
+    if args.sustain_s > 0:
+        step_s = elapsed / args.steps
+        chunk = max(1, int(round(1.0 / step_s)))
+        n_chunks = max(2, int(np.ceil(args.sustain_s / (chunk * step_s))))
+        model.profile_select(["fc1_gemm"])
+        model.profile_enable(chunk)          # every read below rewinds the event pool
+        marks, fc1_marks = [], []
+        fence()
+        t0s = time.perf_counter()
+        for _ in range(n_chunks):
+            for _ in range(chunk):
+                step()
+            if use_rccl:
+                torch.cuda.synchronize()
+            pkg.binding.check(L.vh_device_sync(), "sync")
+            marks.append(time.perf_counter() - t0s)
+            ms_c, cnt_c = model.profile_read()["fc1_gemm"]
+            fc1_marks.append(ms_c / max(cnt_c, 1))
+        model.profile_enable(0)
+        model.profile_select(None)
+        total_s = marks[-1]
+
+        def window(lo_s, hi_s):
+            """chunks that END inside (lo_s, hi_s]: images/s per GPU and mean fc1 ms over them"""
+            idx = [k for k, t in enumerate(marks) if lo_s < t <= hi_s] or [len(marks) - 1]
+            t_begin = marks[idx[0] - 1] if idx[0] > 0 else 0.0
+            rate = len(idx) * chunk * B / (marks[idx[-1]] - t_begin)
+            return rate, float(np.mean([fc1_marks[k] for k in idx]))
+        first_rate, first_fc1 = window(0.0, 5.0)
+        last_rate, last_fc1 = window(total_s - 5.0, total_s)
+        if comm is not None:     # slowest rank decides, as for `value`
+            first_rate = B * chunk / comm.max_over_ranks(B * chunk / first_rate)
+            last_rate = B * chunk / comm.max_over_ranks(B * chunk / last_rate)
+        sustained = {"what": f"the same step repeated for {total_s:.1f} s behind the timed region ({chunk * n_chunks} steps, host "
+                             f"sync every {chunk}); whole-job images/sec over the first and the last 5 s, fc1 ms per launch "
+                             "(HIP events) as the clock proxy",
+                     "seconds": round(total_s, 2), "steps": chunk * n_chunks,
+                     "first_5s": {"value": round(world * first_rate, 1), "fc1_ms": round(first_fc1, 4)},
+                     "last_5s": {"value": round(world * last_rate, 1), "fc1_ms": round(last_fc1, 4)},
+                     "mean": round(world * B * chunk * n_chunks / total_s, 1), "unit": "images/sec"}
 
     failed = None
     if rank == 0:

@@ -312,6 +312,18 @@ int vh_launch_linear_planes_norm(vh_stream_t s, void *output, int output_planes,
 int vh_launch_linear_planes_resid_norm(vh_stream_t s, float *output, const void *weight_planes, const void *input_planes,
                                        const float *bias, const float *residual, int rowA, int colA, int colB,
                                        void *operand_out, void *operand_scales_out, float *row_stats_out);
+/* the same three on the exact THREE-part planes (the fp32 path's lab variant, $VIT_HIP_LN_FOLD=1): six-product arithmetic on the
+ * un-normalised rows; output_planes 0 (fp32 rows) or 1 (three-part planes) */
+int vh_launch_colsum_planes3(vh_stream_t s, const void *planes3, float *out, int out_features, int in_features);
+int vh_launch_patch_embed_planes3_norm(vh_stream_t s, const float *images, const void *conv_w_planes3, const float *conv_b,
+                                       const float *cls_token, const float *pos_embed, float *tokens, int n_images, int in_chans,
+                                       int img_size, int patch_size, int embed_dim, void *workspace, size_t workspace_bytes,
+                                       void *operand_planes3_out, float *row_stats_out);
+int vh_launch_linear_p3_norm(vh_stream_t s, void *output, int output_planes, const void *weight_planes3, const void *input_planes3,
+                             const float *row_stats, const float *colsum, const float *bias_folded, double eps, int rowA, int colA,
+                             int colB, int doGelu);
+int vh_launch_linear_p3_resid_norm(vh_stream_t s, float *output, const void *weight_planes3, const void *input_planes3, const float *bias,
+                                   const float *residual, int rowA, int colA, int colB, void *operand_planes3_out, float *row_stats_out);
 /* the same two on block-scaled fp8 operands.  output_kind: 0 fp32 rows, 1 MX tensor (the only kind doGelu takes), 2 one-part
  * fp16 planes */
 int vh_launch_linear_mx_norm(vh_stream_t s, void *output, void *output_scales, int output_kind, const void *weight_values,

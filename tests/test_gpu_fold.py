@@ -315,6 +315,28 @@ def test_model_with_folded_layernorms_one_launch_left_and_inside_the_modes_toler
     assert np.abs(lf - lu).max() <= bound
 
 
+def test_fp32_path_with_folded_layernorms_lab_variant_keeps_the_parity(pkg, device, weights, golden_full, monkeypatch):
+    """$VIT_HIP_LN_FOLD=1 on the fp32 path (a LAB VARIANT, off by default: docs/LABBOOK.md R4.6): the same fold on the exact
+    three-part planes -- x itself is split, gamma sits in the three-part weights, QKV and fc1 apply the row terms.  The
+    reference's goldens (4 synthetic images and its one real image) within the north star's 1e-4 with the same arg-max,
+    one LayerNorm launch left; the difference to the default path is printed."""
+    cfg = pkg.preset("vit_b_16")
+    real = np.load(__import__("pathlib").Path(__file__).resolve().parent / "golden" / "b16_real_image.npz")
+    images = np.concatenate([np.stack([pkg.synth_images(cfg, i, 1)[0] for i in range(4)]), real["image"][None]])
+    want = np.concatenate([golden_full["logits"][:4], real["logits"]])
+    lf, pf = _model_logits(pkg, cfg, weights, images, "f32", True, monkeypatch)
+    monkeypatch.delenv("VIT_HIP_LN_FOLD")
+    m = pkg.ViTHip(cfg, weights, device=0, max_batch=5)
+    assert not pkg.lib().vit_hip_ln_fold(m.ctx)                  # the default fp32 path never folds
+    ld, _ = m.forward(images)
+    m.close()
+    assert pf["layer_norm"][1] == 1
+    ef, ed = np.abs(lf - want).max(axis=1), np.abs(ld - want).max(axis=1)
+    print(f"\nfp32 path, max |dlogit| vs ViT_seq.c per image (4 synthetic + the real one): folded {ef}, default {ed}; "
+          f"folded vs default {np.abs(lf - ld).max():.3e}")
+    assert ef.max() <= 1e-4 and np.array_equal(lf.argmax(1), want.argmax(1))
+
+
 def test_fold_launchers_reject_bad_arguments(pkg, device):
     L = pkg.lib()
     buf = pkg.DeviceBuffer(4096)

@@ -337,11 +337,15 @@ static int fill_weights(vit_hip_ctx *ctx, const Network *networks)
                     break;
                 if (ctx->precision == VIT_PRECISION_BF16_GEMM)
                     rc = vh_launch_split_rows(ctx->stream, d_scaled, ctx->w16[idx], out_f, in_f, 1);
+                else if (ctx->precision == VIT_PRECISION_F32)
+                    rc = vh_launch_split3_planes(ctx->stream, d_scaled, ctx->w3[idx], out_f, in_f);
                 else
                     rc = vh_launch_quantize_mx_rows(ctx->stream, d_scaled, ctx->w8[idx], ctx->w8s[idx], out_f, in_f);
                 if (rc == 0)
                     rc = ctx->precision == VIT_PRECISION_BF16_GEMM
                              ? vh_launch_colsum_operand(ctx->stream, ctx->w16[idx], NULL, ctx->fold_cs[idx], out_f, in_f)
+                         : ctx->precision == VIT_PRECISION_F32
+                             ? vh_launch_colsum_planes3(ctx->stream, ctx->w3[idx], ctx->fold_cs[idx], out_f, in_f)
                              : vh_launch_colsum_operand(ctx->stream, ctx->w8[idx], ctx->w8s[idx], ctx->fold_cs[idx], out_f, in_f);
                 if (rc == 0)
                     rc = vh_launch_fold_bias(ctx->stream, ctx->w[idx], beta, ctx->w[idx + 1], ctx->fold_b[idx], out_f, in_f);
@@ -418,6 +422,13 @@ int vit_hip_ln_fold(const vit_hip_ctx *ctx) { return ctx ? ctx->ln_fold : 0; }
 static int want_ln_fold(const vit_config *cfg, int precision)
 {
     const char *env = getenv("VIT_HIP_LN_FOLD");
+    if (precision == VIT_PRECISION_F32) {
+        /* LAB VARIANT, off unless asked for ($VIT_HIP_LN_FOLD=1): the same fold on the exact three-part planes.  It keeps the
+         * 1e-4 parity on the goldens, but puts it behind the x - mean cancellation for ~1 % (docs/LABBOOK.md R4.6). */
+        const char *p3 = getenv("VIT_HIP_P3"), *native = getenv("VIT_HIP_GEMM_FP32");
+        return env && env[0] == '1' && !(p3 && p3[0] == '0') && !(native && native[0] == 'n') && cfg->embed_dim % 128 == 0 &&
+               cfg->mlp_hidden % 128 == 0 && cfg->embed_dim / 128 <= 16;
+    }
     if (precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM)
         return 0;
     if (env && env[0] == '0')
@@ -453,7 +464,8 @@ static int ctx_new(vit_hip_ctx **out, const vit_config *cfg, int n_tensors, int 
         return 2;
     if (cfg->embed_dim % cfg->num_heads != 0 || cfg->img_size % cfg->patch_size != 0)
         return 2;
-    if (ln_fold && ((precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM) || cfg->embed_dim % 128 != 0))
+    if (ln_fold && ((precision != VIT_PRECISION_BF16_GEMM && precision != VIT_PRECISION_FP8_GEMM && precision != VIT_PRECISION_F32) ||
+                    cfg->embed_dim % 128 != 0))
         return 2;
     vit_hip_ctx *ctx = (vit_hip_ctx *)calloc(1, sizeof(*ctx));
     if (!ctx)
@@ -741,9 +753,11 @@ static int alloc_arena(vit_hip_ctx *ctx)
         ctx->use_p3 = ctx->w3_slab && precision == VIT_PRECISION_F32 && !(env_p3 && env_p3[0] == '0') &&
                       !(env_native && env_native[0] == 'n') && rows * 64 <= 0xffffffffull;
     }
+    if (precision == VIT_PRECISION_F32 && ctx->ln_fold && !ctx->use_p3)
+        return vh_set_error(2, "vit_hip_create: $VIT_HIP_LN_FOLD=1 on the fp32 path needs the planes path (batch too large for it)");
     {
         const char *env_ll = getenv("VIT_HIP_LAST_LAYER");
-        ctx->cls_only_last = ctx->use_p3 && env_ll && strcmp(env_ll, "cls") == 0;
+        ctx->cls_only_last = ctx->use_p3 && !ctx->ln_fold && env_ll && strcmp(env_ll, "cls") == 0;
     }
     const size_t act = ctx->use_p3 ? 6 : sizeof(float);   /* bytes per GEMM-input value */
     TRY(vh_malloc((void **)&ctx->x, rows * E * sizeof(float)));
@@ -795,7 +809,10 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     /* ln_fold (reduced modes): y holds the residual rows x as the next projection's operand -- one-part bf16 planes, or MX
      * values with their scales behind them -- and stats their partial sums; both are written by whoever writes x */
     char *const y_scales = (char *)ctx->y + align_up((size_t)rows * E, 256);
-    if (fold)
+    if (fold && ctx->precision == VIT_PRECISION_F32)   /* lab variant: the fold on three-part planes */
+        OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_planes3_norm(s, d_images, ctx->wconv16, w[2], w[0], w[3], ctx->x, n, c->in_chans,
+                                                                  c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes, ctx->y, ctx->stats));
+    else if (fold)
         OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_planes_norm(s, d_images, ctx->wconv16, w[2], w[0], w[3], ctx->x, n, c->in_chans,
                                                                  c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes, ctx->y,
                                                                  ctx->precision == VIT_PRECISION_FP8_GEMM ? y_scales : NULL, ctx->stats));
@@ -941,6 +958,27 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
         /* GEMM inputs as pre-split planes: LayerNorm, attention and the fc1 epilogue write them */
         float **lw = w + 4 + 12 * l;
         void **l3 = ctx->w3 + 4 + 12 * l;
+        if (fold) {
+            /* LAB VARIANT ($VIT_HIP_LN_FOLD=1): the reduced modes' LayerNorm fold (csrc/norm_fold.h) on the exact three-part
+             * planes -- ctx->y holds the split of x itself, QKV and fc1 apply the row terms */
+            const float *cs_in = ctx->fold_cs[4 + 12 * l + 2], *bf_in = ctx->fold_b[4 + 12 * l + 2];
+            const float *cs_f1 = ctx->fold_cs[4 + 12 * l + 8], *bf_f1 = ctx->fold_b[4 + 12 * l + 8];
+            if (E == 64 * c->num_heads && T <= 208) {
+                OP(VIT_OP_QKV, vh_launch_linear_p3_norm(s, ctx->qkv, 1, l3[2], ctx->y, ctx->stats, cs_in, bf_in, c->eps, rows, E, 3 * E, 0));
+                OP(VIT_OP_ATTENTION, vh_launch_attention_planes(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+            } else {
+                OP(VIT_OP_QKV, vh_launch_linear_p3_norm(s, ctx->qkv, 0, l3[2], ctx->y, ctx->stats, cs_in, bf_in, c->eps, rows, E, 3 * E, 0));
+                OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
+                                     vh_launch_split3_rows(s, ctx->hid, ctx->attn, rows, E));
+            }
+            OP(VIT_OP_OUT_PROJ, vh_launch_linear_p3_resid_norm(s, ctx->x, l3[4], ctx->attn, lw[5], ctx->x, rows, E, E, ctx->y, ctx->stats));
+            OP(VIT_OP_FC1, vh_launch_linear_p3_norm(s, ctx->hid, 1, l3[8], ctx->y, ctx->stats, cs_f1, bf_f1, c->eps, rows, E, F, 1));
+            if (l == c->depth - 1)
+                OP(VIT_OP_FC2, vh_launch_linear_p3(s, ctx->x, 0, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+            else
+                OP(VIT_OP_FC2, vh_launch_linear_p3_resid_norm(s, ctx->x, l3[10], ctx->hid, lw[11], ctx->x, rows, F, E, ctx->y, ctx->stats));
+            continue;
+        }
         OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, c->eps));
         if (E == 64 * c->num_heads && T <= 208) {
             /* Q, K, V too travel as planes: only the probabilities are split inside the attention kernel */
@@ -1010,7 +1048,7 @@ int vit_hip_set_last_layer_cls_only(vit_hip_ctx *ctx, int on)
     if (!ctx)
         return -1;
     const int before = ctx->cls_only_last;
-    ctx->cls_only_last = on && ctx->use_p3;
+    ctx->cls_only_last = on && ctx->use_p3 && !ctx->ln_fold;
     return before;
 }
 

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
     constexpr bool OPER = OUTK == OUT_F32_OPER || OUTK == OUT_F32_OPER_MX;
     static_assert(NPL == 1 || NPL == 3, "parts per value");
     static_assert(JT % 2 == 0 && (KG * NPL * BN / 16) % NW == 0 && F % RING == 0, "tile shape");
-    static_assert(!(NORM || OPER) || NPL == 1, "the folded LayerNorm belongs to the one-part (reduced) modes");
+    static_assert(OUTK != OUT_F32_OPER_MX || NPL == 1, "an MX operand follows one-part operands only");
     static_assert(!OPER || (BN % 128 == 0 && (EPI == EPI_RESID || EPI == EPI_PATCH)), "operand producers: residual-stream epilogues");
     typedef bf16x8 frag_t;
 
@@ -355,13 +355,19 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_p3_kernel(const P3Params p)
                 psum[i] = psum[i] + v;
                 psq[i] = __builtin_elementwise_fma(v, v, psq[i]);
             }
-            if (OUTK == OUT_F32_OPER) {
-                frag_t part;
+            if (OUTK == OUT_F32_OPER) {   /* planes [N/32][NPL][c_rows][32]: one rounded part, or the exact three-part split */
+                frag_t part[3];
+                if (NPL == 3) {
+                    split8(lo, hi, part[0], part[1], part[2]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    part[e] = (__bf16)(e < 4 ? lo[e] : hi[e - 4]);
-                *reinterpret_cast<f32x4 *>(static_cast<char *>(p.oper) + ((size_t)((n0 >> 5) + s) * p.c_rows + orow_[i]) * 64 + 16 * q) =
-                    __builtin_bit_cast(f32x4, part);
+                    for (int e = 0; e < 8; ++e)
+                        part[0][e] = (__bf16)(e < 4 ? lo[e] : hi[e - 4]);
+                }
+                char *dst = static_cast<char *>(p.oper) + ((size_t)((n0 >> 5) + s) * NPL * p.c_rows + orow_[i]) * 64 + 16 * q;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    *reinterpret_cast<f32x4 *>(dst + (size_t)pl * p.c_rows * 64) = __builtin_bit_cast(f32x4, part[pl]);
             } else {
                 mx_store_block8(lo, hi, static_cast<char *>(p.oper), static_cast<unsigned char *>(p.oper_scales), p.c_rows, orow_[i],
                                 n0 + 32 * s, q, true);
@@ -619,15 +625,16 @@ extern "C" int vh_launch_linear_p3(vh_stream_t s, void *output, int output_plane
 /* LN(A) W^T + b with the LayerNorm folded: `input_planes` = the UN-normalised rows as one-part bf16 planes, `row_stats` =
  * their partial sums [colA/128][rowA][2], `weight_planes` = the gamma-scaled weights, `colsum` / `bias_folded` the column
  * terms (vh_launch_fold_* below).  output_planes: 0 fp32 rows, 1 bf16 planes, 2 fp16 planes (as vh_launch_linear_planes). */
-extern "C" int vh_launch_linear_planes_norm(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
-                                            const void *input_planes, const float *row_stats, const float *colsum,
-                                            const float *bias_folded, double eps, int rowA, int colA, int colB, int doGelu)
+static int linear_planes_norm(vh_stream_t s, void *output, int output_planes, const void *weight_planes, const void *input_planes,
+                              const float *row_stats, const float *colsum, const float *bias_folded, double eps, int rowA, int colA,
+                              int colB, int doGelu, int parts)
 {
     if (!output || !weight_planes || !input_planes || !row_stats || !colsum || !bias_folded)
         return vh_fail(1, "vh_launch_linear_planes_norm: null pointer argument");
-    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % (64 * P1_KG) != 0 || colB % 128 != 0)
-        return vh_fail(1, "vh_launch_linear_planes_norm: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", 64 * P1_KG, rowA, colA, colB);
-    if (output_planes < 0 || output_planes > 2 || (output_planes == 2 && doGelu) || (output_planes == 0 && doGelu))
+    const int kstep = parts == 3 ? 64 : 64 * P1_KG;
+    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % kstep != 0 || colB % 128 != 0)
+        return vh_fail(1, "vh_launch_linear_planes_norm: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", kstep, rowA, colA, colB);
+    if (output_planes < 0 || output_planes > 2 || (output_planes == 2 && (doGelu || parts == 3)) || (output_planes == 0 && doGelu))
         return vh_fail(1, "vh_launch_linear_planes_norm: unsupported epilogue combination");
     if (colA > 16 * 128)
         return vh_fail(1, "vh_launch_linear_planes_norm: colA=%d: at most 16 partial sums per row (colA <= 2048)", colA);
@@ -643,23 +650,47 @@ extern "C" int vh_launch_linear_planes_norm(vh_stream_t s, void *output, int out
     p.row_begin = 0; p.row_end = rowA; p.a_rows = rowA; p.c_rows = rowA;
     p.N = colB; p.K = colA;
     hipStream_t st = (hipStream_t)s;
+    if (parts == 3) {
+        if (doGelu)
+            return launch_p3<EPI_NORM_GELU, OUT_PLANES, 3>(st, p, 0);
+        return output_planes == 1 ? launch_p3<EPI_NORM, OUT_PLANES, 3>(st, p, 0) : launch_p3<EPI_NORM, OUT_F32, 3>(st, p, 0);
+    }
     if (doGelu)
         return launch_p3<EPI_NORM_GELU, OUT_PLANES, 1>(st, p, 0);
     return output_planes == 2 ? launch_p3<EPI_NORM, OUT_PLANES_H, 1>(st, p, 0)
          : output_planes == 1 ? launch_p3<EPI_NORM, OUT_PLANES, 1>(st, p, 0) : launch_p3<EPI_NORM, OUT_F32, 1>(st, p, 0);
 }
 
+extern "C" int vh_launch_linear_planes_norm(vh_stream_t s, void *output, int output_planes, const void *weight_planes,
+                                            const void *input_planes, const float *row_stats, const float *colsum,
+                                            const float *bias_folded, double eps, int rowA, int colA, int colB, int doGelu)
+{
+    return linear_planes_norm(s, output, output_planes, weight_planes, input_planes, row_stats, colsum, bias_folded, eps, rowA, colA, colB,
+                              doGelu, 1);
+}
+
+/* the same on three-part planes (the fp32 path as a LAB VARIANT, $VIT_HIP_LN_FOLD=1): exact six-product arithmetic, the
+ * un-normalised rows as the operand; output_planes 0 (fp32 rows) or 1 (three-part planes) */
+extern "C" int vh_launch_linear_p3_norm(vh_stream_t s, void *output, int output_planes, const void *weight_planes3,
+                                        const void *input_planes3, const float *row_stats, const float *colsum,
+                                        const float *bias_folded, double eps, int rowA, int colA, int colB, int doGelu)
+{
+    return linear_planes_norm(s, output, output_planes, weight_planes3, input_planes3, row_stats, colsum, bias_folded, eps, rowA, colA, colB,
+                              doGelu, 3);
+}
+
 /* output = residual + A W^T + b (fp32 rows, in place allowed) AND the same rows as the next projection's operand:
  * one-part bf16 planes [colB/32][rowA][32] (operand_scales NULL) or MX values + scales, plus the rows' partial sums
  * row_stats_out [colB/128][rowA][2] for that projection's folded LayerNorm. */
-extern "C" int vh_launch_linear_planes_resid_norm(vh_stream_t s, float *output, const void *weight_planes, const void *input_planes,
-                                                  const float *bias, const float *residual, int rowA, int colA, int colB,
-                                                  void *operand_out, void *operand_scales_out, float *row_stats_out)
+static int linear_planes_resid_norm(vh_stream_t s, float *output, const void *weight_planes, const void *input_planes, const float *bias,
+                                    const float *residual, int rowA, int colA, int colB, void *operand_out, void *operand_scales_out,
+                                    float *row_stats_out, int parts)
 {
     if (!output || !weight_planes || !input_planes || !bias || !residual || !operand_out || !row_stats_out)
         return vh_fail(1, "vh_launch_linear_planes_resid_norm: null pointer argument");
-    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % (64 * P1_KG) != 0 || colB % 128 != 0)
-        return vh_fail(1, "vh_launch_linear_planes_resid_norm: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", 64 * P1_KG, rowA, colA, colB);
+    const int kstep = parts == 3 ? 64 : 64 * P1_KG;
+    if (rowA <= 0 || colA <= 0 || colB <= 0 || colA % kstep != 0 || colB % 128 != 0 || (parts == 3 && operand_scales_out))
+        return vh_fail(1, "vh_launch_linear_planes_resid_norm: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", kstep, rowA, colA, colB);
     if ((((uintptr_t)output | (uintptr_t)weight_planes | (uintptr_t)input_planes | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)operand_out) & 15) != 0 ||
         ((uintptr_t)row_stats_out & 7) != 0)
         return vh_fail(1, "vh_launch_linear_planes_resid_norm: pointers must be 16-byte aligned (row_stats_out: 8)");
@@ -674,11 +705,47 @@ extern "C" int vh_launch_linear_planes_resid_norm(vh_stream_t s, float *output, 
     p.N = colB; p.K = colA;
     hipStream_t st = (hipStream_t)s;
     const int small_only = colA < 2048;   /* as vh_launch_linear_planes: the N = K = E output projection */
+    if (parts == 3)
+        return launch_p3<EPI_RESID, OUT_F32_OPER, 3>(st, p, small_only);
     return operand_scales_out ? launch_p3<EPI_RESID, OUT_F32_OPER_MX, 1>(st, p, small_only)
                               : launch_p3<EPI_RESID, OUT_F32_OPER, 1>(st, p, small_only);
 }
 
+extern "C" int vh_launch_linear_planes_resid_norm(vh_stream_t s, float *output, const void *weight_planes, const void *input_planes,
+                                                  const float *bias, const float *residual, int rowA, int colA, int colB,
+                                                  void *operand_out, void *operand_scales_out, float *row_stats_out)
+{
+    return linear_planes_resid_norm(s, output, weight_planes, input_planes, bias, residual, rowA, colA, colB, operand_out,
+                                    operand_scales_out, row_stats_out, 1);
+}
+
+/* the same on three-part planes (fp32 lab variant): fp32 rows + the exact three-part planes of the same rows + partial sums */
+extern "C" int vh_launch_linear_p3_resid_norm(vh_stream_t s, float *output, const void *weight_planes3, const void *input_planes3,
+                                              const float *bias, const float *residual, int rowA, int colA, int colB,
+                                              void *operand_planes3_out, float *row_stats_out)
+{
+    return linear_planes_resid_norm(s, output, weight_planes3, input_planes3, bias, residual, rowA, colA, colB, operand_planes3_out,
+                                    nullptr, row_stats_out, 3);
+}
+
 namespace {
+
+/* eight consecutive k of row m (chunk c of K step kt) -> the NPL parts of planes[K/32][NPL][rows][32] */
+template <int NPL>
+__device__ __forceinline__ void store_parts8(char *planes, size_t kt, int rows, int m, int c, const f32x4 &u, const f32x4 &v)
+{
+    bf16x8 part[3];
+    if (NPL == 3) {
+        split8(u, v, part[0], part[1], part[2]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            part[0][e] = (__bf16)(e < 4 ? u[e] : v[e - 4]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+        *reinterpret_cast<f32x4 *>(planes + ((kt * NPL + pl) * rows + m) * 64 + 16 * c) = __builtin_bit_cast(f32x4, part[pl]);
+}
 
 /* One wave per weight row n (Linear layout [N][K]).  MODE 0: out[n][k] = w[n][k] * gamma[k] (the gamma-scaled matrix, fp32,
  * before the mode's rounding).  MODE 1: out[n] = bias[n] + sum_k beta[k] w[n][k] (the folded bias; double accumulation). */
@@ -705,10 +772,11 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const float *__restrict_
     }
 }
 
-/* colsum[n] = sum_k of the operand's OWN values (what the matrix cores multiply): one-part bf16 planes [K/32][1][N][32]
- * (scales == nullptr) or MX values [K/128][N][128] with scales [K/128][4][N].  One wave per row n, double accumulation. */
+/* colsum[n] = sum_k of the operand's OWN values (what the matrix cores multiply): bf16 planes [K/32][parts][N][32]
+ * (scales == nullptr; parts 1, or 3: the parts of a value added) or MX values [K/128][N][128] with scales [K/128][4][N].
+ * One wave per row n, double accumulation. */
 __global__ __launch_bounds__(256) void colsum_operand_kernel(const char *__restrict__ values, const unsigned char *__restrict__ scales,
-                                                            float *__restrict__ out, int N, int K)
+                                                            float *__restrict__ out, int N, int K, int parts)
 {
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N)
@@ -716,7 +784,8 @@ __global__ __launch_bounds__(256) void colsum_operand_kernel(const char *__restr
     double acc = 0.0;
     if (!scales) {
         for (int k = lane; k < K; k += 64)
-            acc += (double)(float)*reinterpret_cast<const __bf16 *>(values + ((size_t)(k >> 5) * N + n) * 64 + 2 * (k & 31));
+            for (int pl = 0; pl < parts; ++pl)
+                acc += (double)(float)*reinterpret_cast<const __bf16 *>(values + (((size_t)(k >> 5) * parts + pl) * N + n) * 64 + 2 * (k & 31));
     } else {
         for (int k = lane; k < K; k += 64) {
             const int ks = k >> 7, blk = (k >> 5) & 3;
@@ -739,6 +808,7 @@ __global__ __launch_bounds__(256) void colsum_operand_kernel(const char *__restr
 
 /* Token 0 of every image (class token + pos_embed[0], ViT_seq.c:90-93,114-117) for the folded path: the fp32 row, the
  * row as the next projection's operand and its partial sums.  One wave per (16 images, 128-column group g). */
+template <int NPL>   /* parts of the planes operand (oper_scales == nullptr): 1 rounded, 3 exact */
 __global__ __launch_bounds__(64) void cls_rows_operand_kernel(const float *__restrict__ cls, const float *__restrict__ pos,
                                                              float *__restrict__ tokens, char *__restrict__ oper,
                                                              unsigned char *__restrict__ oper_scales, float *__restrict__ stats,
@@ -767,12 +837,8 @@ __global__ __launch_bounds__(64) void cls_rows_operand_kernel(const float *__res
             *reinterpret_cast<f32x4 *>(tokens + row * E + col + 4) = hi;
         }
         if (!oper_scales) {
-            bf16x8 part;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                part[e] = (__bf16)(e < 4 ? lo[e] : hi[e - 4]);
             if (live)
-                *reinterpret_cast<f32x4 *>(oper + ((size_t)(col >> 5) * c_rows + row) * 64 + 16 * j) = __builtin_bit_cast(f32x4, part);
+                store_parts8<NPL>(oper, (size_t)(col >> 5), c_rows, (int)row, j, lo, hi);
         } else {
             mx_store_block8(lo, hi, oper, oper_scales, c_rows, row, 128 * g + 32 * s, j, live);
         }
@@ -811,14 +877,25 @@ extern "C" int vh_launch_fold_bias(vh_stream_t s, const float *weight, const flo
 }
 
 /* out[n] = sum_k of the values the operand holds for weight row n: one-part bf16 planes (scales NULL) or MX values + scales */
-extern "C" int vh_launch_colsum_operand(vh_stream_t s, const void *values, const void *scales, float *out, int out_features, int in_features)
+static int colsum_operand(vh_stream_t s, const void *values, const void *scales, float *out, int out_features, int in_features, int parts)
 {
     if (!values || !out || out_features <= 0 || in_features <= 0 || in_features % (scales ? 128 : 32) != 0)
         return vh_fail(1, "vh_launch_colsum_operand: bad argument");
     hipLaunchKernelGGL(colsum_operand_kernel, dim3((out_features + 3) / 4), dim3(256), 0, (hipStream_t)s, static_cast<const char *>(values),
-                       static_cast<const unsigned char *>(scales), out, out_features, in_features);
+                       static_cast<const unsigned char *>(scales), out, out_features, in_features, parts);
     VH_LAUNCH_CHECK("colsum_operand_kernel");
     return 0;
+}
+
+extern "C" int vh_launch_colsum_operand(vh_stream_t s, const void *values, const void *scales, float *out, int out_features, int in_features)
+{
+    return colsum_operand(s, values, scales, out, out_features, in_features, 1);
+}
+
+/* the same for three-part planes [K/32][3][N][32] (the fp32 path's weights): the parts of a value added */
+extern "C" int vh_launch_colsum_planes3(vh_stream_t s, const void *planes3, float *out, int out_features, int in_features)
+{
+    return colsum_operand(s, planes3, nullptr, out, out_features, in_features, 3);
 }
 
 /* ---- patch embedding on one-part planes (the reduced modes' conv_proj; replaces conv2d.cl:1-80 for them) ----
@@ -827,23 +904,6 @@ extern "C" int vh_launch_colsum_operand(vh_stream_t s, const void *values, const
  * to bf16 once -- and the patch embedding is the planes GEMM with a token-row epilogue: K padded with zeros to the
  * one-part K step (ViT-H/14: 3*14*14 = 588 -> 640), conv weights padded and rounded alike at context creation. */
 namespace {
-
-/* eight consecutive k of row m (chunk c of K step kt) -> the NPL parts of planes[K/32][NPL][rows][32] */
-template <int NPL>
-__device__ __forceinline__ void store_parts8(char *planes, size_t kt, int rows, int m, int c, const f32x4 &u, const f32x4 &v)
-{
-    bf16x8 part[3];
-    if (NPL == 3) {
-        split8(u, v, part[0], part[1], part[2]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            part[0][e] = (__bf16)(e < 4 ? u[e] : v[e - 4]);
-    }
-#pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
-        *reinterpret_cast<f32x4 *>(planes + ((kt * NPL + pl) * rows + m) * 64 + 16 * c) = __builtin_bit_cast(f32x4, part[pl]);
-}
 
 /* Thread i writes bytes [16 i, 16 i + 16) of planes[Kp/32][1][n_rows][32]: (K step kt, row m, chunk c) with c fastest
  * -- stores are contiguous; for patch % 8 == 0 a lane's eight k are 32 contiguous bytes of one image row and the
@@ -952,8 +1012,8 @@ static int patch_embed_planes(vh_stream_t s, const float *images, const void *co
     const int grid = img_size / patch_size, K = in_chans * patch_size * patch_size, Kp = vh_patch_planes_k(in_chans, patch_size);
     const long M = (long)n_images * grid * grid;
     const long c_rows = (long)n_images * (grid * grid + 1);
-    if ((parts != 1 && parts != 3) || (parts == 3 && operand_out))
-        return vh_fail(1, "vh_launch_patch_embed_planes: parts must be 1 (bf16 operands) or 3 (exact fp32 split, no folded operand)");
+    if ((parts != 1 && parts != 3) || (parts == 3 && operand_scales_out))
+        return vh_fail(1, "vh_launch_patch_embed_planes: parts must be 1 (bf16 operands) or 3 (exact fp32 split: planes operand only)");
     if (c_rows * 128 > 0xffffffffl || workspace_bytes < (size_t)M * Kp * 2 * parts ||
         (((uintptr_t)workspace | (uintptr_t)conv_w_planes | (uintptr_t)images | (uintptr_t)conv_b | (uintptr_t)pos_embed | (uintptr_t)tokens |
           (uintptr_t)cls_token | (uintptr_t)operand_out) & 15) || ((uintptr_t)row_stats_out & 7))
@@ -962,9 +1022,14 @@ static int patch_embed_planes(vh_stream_t s, const float *images, const void *co
         return vh_fail(1, "vh_launch_patch_embed_planes_norm: operand without row statistics");
     hipStream_t st = (hipStream_t)s;
     if (operand_out) {
-        hipLaunchKernelGGL(cls_rows_operand_kernel, dim3((n_images + 15) / 16, embed_dim / 128), dim3(64), 0, st, cls_token, pos_embed, tokens,
-                           static_cast<char *>(operand_out), static_cast<unsigned char *>(operand_scales_out), row_stats_out, n_images,
-                           grid * grid + 1, embed_dim, (int)c_rows);
+        if (parts == 3)
+            hipLaunchKernelGGL(cls_rows_operand_kernel<3>, dim3((n_images + 15) / 16, embed_dim / 128), dim3(64), 0, st, cls_token, pos_embed,
+                               tokens, static_cast<char *>(operand_out), static_cast<unsigned char *>(operand_scales_out), row_stats_out,
+                               n_images, grid * grid + 1, embed_dim, (int)c_rows);
+        else
+            hipLaunchKernelGGL(cls_rows_operand_kernel<1>, dim3((n_images + 15) / 16, embed_dim / 128), dim3(64), 0, st, cls_token, pos_embed,
+                               tokens, static_cast<char *>(operand_out), static_cast<unsigned char *>(operand_scales_out), row_stats_out,
+                               n_images, grid * grid + 1, embed_dim, (int)c_rows);
         VH_LAUNCH_CHECK("cls_rows_operand_kernel");
     } else if (int rc = vh_cls_rows(st, cls_token, pos_embed, tokens, n_images, grid * grid + 1, embed_dim))
         return rc;
@@ -986,7 +1051,7 @@ static int patch_embed_planes(vh_stream_t s, const float *images, const void *co
     p.oper = operand_out; p.oper_scales = operand_scales_out; p.stats_out = row_stats_out;
     const int small_only = Kp < 2048;   /* the shape of the output projection: small tiles (measured there) */
     if (parts == 3)
-        return launch_p3<EPI_PATCH, OUT_F32, 3>(st, p, small_only);
+        return operand_out ? launch_p3<EPI_PATCH, OUT_F32_OPER, 3>(st, p, small_only) : launch_p3<EPI_PATCH, OUT_F32, 3>(st, p, small_only);
     if (!operand_out)
         return launch_p3<EPI_PATCH, OUT_F32, 1>(st, p, small_only);
     return operand_scales_out ? launch_p3<EPI_PATCH, OUT_F32_OPER_MX, 1>(st, p, small_only) : launch_p3<EPI_PATCH, OUT_F32_OPER, 1>(st, p, small_only);
@@ -1011,6 +1076,18 @@ extern "C" int vh_launch_patch_embed_planes3(vh_stream_t s, const float *images,
 {
     return patch_embed_planes(s, images, conv_w_planes3, conv_b, cls_token, pos_embed, tokens, n_images, in_chans, img_size, patch_size,
                               embed_dim, workspace, workspace_bytes, nullptr, nullptr, nullptr, 3);
+}
+
+/* ... also leaving the token rows as three-part planes [E/32][3][n*tokens][32] + partial sums (fp32 lab variant of the fold) */
+extern "C" int vh_launch_patch_embed_planes3_norm(vh_stream_t s, const float *images, const void *conv_w_planes3, const float *conv_b,
+                                                  const float *cls_token, const float *pos_embed, float *tokens, int n_images,
+                                                  int in_chans, int img_size, int patch_size, int embed_dim, void *workspace,
+                                                  size_t workspace_bytes, void *operand_planes3_out, float *row_stats_out)
+{
+    if (!operand_planes3_out || !row_stats_out)
+        return vh_fail(1, "vh_launch_patch_embed_planes3_norm: null pointer argument");
+    return patch_embed_planes(s, images, conv_w_planes3, conv_b, cls_token, pos_embed, tokens, n_images, in_chans, img_size, patch_size,
+                              embed_dim, workspace, workspace_bytes, operand_planes3_out, nullptr, row_stats_out, 3);
 }
 
 /* The same, also leaving the token rows as the first projection's operand (one-part bf16 planes [E/32][n*tokens][32], or MX

@@ -47,6 +47,7 @@ EXPORTS = [
     "vh_launch_attention_planes_f16_hd80", "vh_launch_attention_planes_f16_hd80_operand",
     "vh_launch_gather_rows", "vit_hip_set_last_layer_cls_only",
     "vh_launch_conv_weight_planes_parts", "vh_launch_patch_embed_planes3",
+    "vh_launch_colsum_planes3", "vh_launch_patch_embed_planes3_norm", "vh_launch_linear_p3_norm", "vh_launch_linear_p3_resid_norm",
     "vh_launch_fold_gamma", "vh_launch_fold_bias", "vh_launch_colsum_operand", "vh_launch_patch_embed_planes_norm",
     "vh_launch_linear_planes_norm", "vh_launch_linear_planes_resid_norm", "vh_launch_linear_mx_norm",
     "vh_launch_linear_mx_resid_norm", "vit_hip_ln_fold",
@@ -190,6 +191,10 @@ def lib() -> C.CDLL:
     L.vh_launch_linear_planes.argtypes = [voidp, voidp, i, voidp, voidp, i, voidp, i, i, i, i, voidp]
     L.vh_launch_conv_weight_planes_parts.argtypes = [voidp, voidp, voidp, i, i, i, i]
     L.vh_launch_patch_embed_planes3.argtypes = [voidp] + [voidp] * 6 + [i] * 5 + [voidp, sz]
+    L.vh_launch_colsum_planes3.argtypes = [voidp, voidp, voidp, i, i]
+    L.vh_launch_patch_embed_planes3_norm.argtypes = [voidp] + [voidp] * 6 + [i] * 5 + [voidp, sz, voidp, voidp]
+    L.vh_launch_linear_p3_norm.argtypes = [voidp, voidp, i, voidp, voidp, voidp, voidp, voidp, C.c_double, i, i, i, i]
+    L.vh_launch_linear_p3_resid_norm.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, i, i, i, voidp, voidp]
     L.vh_launch_fold_gamma.argtypes = [voidp, voidp, voidp, voidp, i, i]
     L.vh_launch_fold_bias.argtypes = [voidp, voidp, voidp, voidp, voidp, i, i]
     L.vh_launch_colsum_operand.argtypes = [voidp, voidp, voidp, voidp, i, i]
