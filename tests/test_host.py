@@ -265,6 +265,44 @@ def test_shards_are_entered_concurrently_and_timed(pkg):
     assert L.vit_shard_run_timed(4, 4, b.SHARD_FN(slow_or_fail), None, None) == 5      # the times are optional
 
 
+def test_planes_file_header_is_checked_before_anything_is_allocated(pkg, tmp_path):
+    """vit_hip_create_from_planes on files that must be refused -- without a GPU, i.e. before the library has touched a
+    device or allocated a slab: a foreign file, another operand-layout version, a header asking for absurd dimensions
+    (a corrupt or hostile file must not be able to request arbitrary host and HBM allocations), and a header whose slab
+    sizes are not the ones this library derives from (shape, precision, fold flag)."""
+    import struct
+    L, b = pkg.lib(), pkg.binding
+    L.vit_hip_create_from_planes.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int]
+    FMT = "<8sIii8i4xd4QQiiQ"
+    assert struct.calcsize(FMT) == 120
+
+    def header(magic=b"VITPLN02", precision=0, n_tensors=152, ints=(224, 16, 3, 1000, 768, 12, 12, 3072), sizes=(1, 1, 1, 152), fold=(0, 0),
+               version=2):
+        return struct.pack(FMT, magic, 120, precision, n_tensors, *ints, 1e-6, *sizes, fold[0], fold[1], version, 0)
+
+    def load(blob):
+        path = tmp_path / "x.planes"
+        path.write_bytes(blob + b"\0" * 4096)
+        ctx = C.c_void_p()
+        rc = L.vit_hip_create_from_planes(C.byref(ctx), str(path).encode(), 0, 4)
+        assert not ctx.value
+        return rc, L.vh_last_error().decode()
+    rc, msg = load(header(magic=b"VITPLN01"))
+    assert rc == 124 and "not a planes file" in msg
+    rc, msg = load(header(version=1))
+    assert rc == 124
+    rc, msg = load(header(ints=(224, 16, 3, 1000, 768, 100000, 12, 3072), n_tensors=4 + 12 * 100000 + 4))
+    assert rc != 0 and "shape or precision" in msg                      # depth 100 000: refused, nothing allocated
+    rc, msg = load(header(ints=(224, 16, 3, 1000, 1 << 20, 12, 12, 3072)))
+    assert rc != 0 and "shape or precision" in msg                      # embed_dim 2^20
+    rc, msg = load(header(sizes=(1 << 50, 1 << 50, 0, 152)))
+    assert rc == 125 and "slab sizes" in msg                             # a petabyte of weights: refused by the size check
+    rc, msg = load(header(precision=7))
+    assert rc != 0
+    ctx = C.c_void_p()
+    assert L.vit_hip_create_from_planes(C.byref(ctx), str(tmp_path / "missing.planes").encode(), 0, 4) == 123
+
+
 def test_fp8_reference_round_trips_every_code():
     """tests/fp8_ref.py (the numpy statement of OCP e4m3 the GPU casts are checked against):
     every finite code survives dequantise -> quantise, ties go to the even code, overflow

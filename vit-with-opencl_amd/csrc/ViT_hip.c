@@ -160,7 +160,9 @@ void vit_hip_destroy(vit_hip_ctx *ctx)
 {
     if (!ctx)
         return;
-    vh_set_device(ctx->device);
+    if (ctx->stream || ctx->w_slab)   /* a context that never reached the device (refused header, bad arguments) leaves the
+                                       * device -- and the caller's error text -- alone */
+        vh_set_device(ctx->device);
     if (ctx->stream)
         vh_stream_sync(ctx->stream);
     prof_release(ctx);
