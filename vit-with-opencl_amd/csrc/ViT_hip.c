@@ -793,28 +793,219 @@ fail:
     return rc;
 }
 
-int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float *d_logits,
-                           float *d_probs, vh_stream_t stream)
+/* ---- one encoder layer per arithmetic (ViT_seq.c:330-370; Encoder ViT_opencl.c:710-748) ------------------------------
+ * Every function enqueues layer l for n images on stream s: y = LN1(x); qkv = y Win^T + bin; a = attention(qkv);
+ * x += a Wout^T + bout; y = LN2(x); h = gelu(y W1^T + b1); x += h W2^T + b2 -- in its mode's operand formats.  With
+ * ctx->ln_fold the two LayerNorms are not launched: whoever wrote x also left it as the projection's operand in ctx->y
+ * with the rows' partial sums in ctx->stats, and the QKV / fc1 launches apply the row terms (csrc/norm_fold.h). */
+
+/* Q|K|V as one-part fp16 planes for the planes attention kernels (head_dim 64 with T <= 208; head_dim 80 with T <= 272:
+ * ViT-H/14), fp32 rows for the streaming kernel */
+static int qkv_as_planes(const vit_hip_ctx *ctx)
+{
+    const int E = ctx->cfg.embed_dim, H = ctx->cfg.num_heads, T = ctx->tokens;
+    return (E == 64 * H && T <= 208) || (E == 80 * H && T <= 272);
+}
+
+/* The reduced modes' attention on fp16-rounded operands, writing the output projection's operand: one-part bf16 planes
+ * (attn_scales NULL) or an MX tensor.  The planes kernels write it themselves; the streaming kernel (and head_dim 80 with
+ * an odd head count) leaves fp32 rows in the idle MLP buffer, which are then rounded / quantised (one timed operator). */
+static int attention_reduced(vit_hip_ctx *ctx, vh_stream_t s, int n, char *attn_scales)
 {
     int rc = 0;
-    if (!ctx || !d_images || n <= 0 || n > ctx->max_batch)
-        return 1;
-    TRY(vh_set_device(ctx->device));   /* the current device is per host thread */
     const vit_config *c = &ctx->cfg;
-    const int E = c->embed_dim, F = c->mlp_hidden, T = ctx->tokens, NC = c->num_classes;
-    const int rows = n * T;
-    vh_stream_t s = stream ? stream : ctx->stream;
-    float **w = ctx->w;
+    const int E = c->embed_dim, T = ctx->tokens, H = c->num_heads, rows = n * T;
+    if (E == 64 * H && T <= 208)
+        OP(VIT_OP_ATTENTION, attn_scales ? vh_launch_attention_planes_f16_mx(s, ctx->qkv, ctx->attn, attn_scales, n, T, E, H)
+                                         : vh_launch_attention_planes_f16(s, ctx->qkv, ctx->attn, 1, n, T, E, H));
+    else if (qkv_as_planes(ctx) && (H & 1) == 0)
+        OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, attn_scales, attn_scales ? 2 : 1, n, T, E, H));
+    else
+        OP(VIT_OP_ATTENTION, (rc = qkv_as_planes(ctx) ? vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, H)
+                                                      : vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, H)) != 0 ? rc :
+                             attn_scales ? vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, attn_scales, rows, E)
+                                         : vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
+    return 0;
+fail:
+    return rc;
+}
 
-    /* patch embedding + class token + position embedding (ViT_seq.c:437-443) */
-    const int fold = ctx->ln_fold;
-    /* ln_fold (reduced modes): y holds the residual rows x as the next projection's operand -- one-part bf16 planes, or MX
-     * values with their scales behind them -- and stats their partial sums; both are written by whoever writes x */
-    char *const y_scales = (char *)ctx->y + align_up((size_t)rows * E, 256);
-    if (fold && ctx->precision == VIT_PRECISION_F32)   /* lab variant: the fold on three-part planes */
+/* FP8_GEMM: y, attn and hid hold MX tensors (values, then the scales, in the same allocations) */
+static int layer_fp8(vit_hip_ctx *ctx, vh_stream_t s, int n, int l)
+{
+    int rc = 0;
+    const vit_config *c = &ctx->cfg;
+    const int E = c->embed_dim, F = c->mlp_hidden, rows = n * ctx->tokens, fold = ctx->ln_fold, last = l == c->depth - 1;
+    float **lw = ctx->w + 4 + 12 * l;
+    void **l8 = ctx->w8 + 4 + 12 * l, **l8s = ctx->w8s + 4 + 12 * l;
+    float **cs = ctx->fold_cs + 4 + 12 * l, **bf = ctx->fold_b + 4 + 12 * l;
+    char *ys = (char *)ctx->y + align_up((size_t)rows * E, 256), *as_ = (char *)ctx->attn + align_up((size_t)rows * E, 256);
+    char *hs = (char *)ctx->hid + align_up((size_t)rows * F, 256);
+    const int kind = qkv_as_planes(ctx) ? 2 : 0;
+    if (!fold)
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[0], lw[1], ctx->y, ys, rows, E, E, c->eps));
+    OP(VIT_OP_QKV, fold ? vh_launch_linear_mx_norm(s, ctx->qkv, NULL, kind, l8[2], l8s[2], ctx->y, ys, ctx->stats, cs[2], bf[2], c->eps, rows, E, 3 * E, 0)
+                 : kind ? vh_launch_linear_mx_planes_f16(s, ctx->qkv, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E)
+                        : vh_launch_linear_mx(s, ctx->qkv, NULL, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E, 0, NULL));
+    TRY(attention_reduced(ctx, s, n, as_));
+    OP(VIT_OP_OUT_PROJ, fold ? vh_launch_linear_mx_resid_norm(s, ctx->x, l8[4], l8s[4], ctx->attn, as_, lw[5], ctx->x, rows, E, E, ctx->y, ys, ctx->stats)
+                             : vh_launch_linear_mx(s, ctx->x, NULL, l8[4], l8s[4], ctx->attn, as_, lw[5], rows, E, E, 0, ctx->x));
+    if (!fold)
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[6], lw[7], ctx->y, ys, rows, E, E, c->eps));
+    OP(VIT_OP_FC1, fold ? vh_launch_linear_mx_norm(s, ctx->hid, hs, 1, l8[8], l8s[8], ctx->y, ys, ctx->stats, cs[8], bf[8], c->eps, rows, E, F, 1)
+                        : vh_launch_linear_mx(s, ctx->hid, hs, l8[8], l8s[8], ctx->y, ys, lw[9], rows, E, F, 1, NULL));
+    /* nothing reads the operand behind the last layer: the final LayerNorm takes the fp32 rows */
+    OP(VIT_OP_FC2, fold && !last ? vh_launch_linear_mx_resid_norm(s, ctx->x, l8[10], l8s[10], ctx->hid, hs, lw[11], ctx->x, rows, F, E, ctx->y, ys, ctx->stats)
+                                 : vh_launch_linear_mx(s, ctx->x, NULL, l8[10], l8s[10], ctx->hid, hs, lw[11], rows, F, E, 0, ctx->x));
+    return 0;
+fail:
+    return rc;
+}
+
+/* BF16_GEMM: operands as one-part planes [K/32][1][rows][32] written by their producers; the fp32 path's kernel with one
+ * product per block (gemm_p3.hip, NPL = 1) */
+static int layer_bf16(vit_hip_ctx *ctx, vh_stream_t s, int n, int l)
+{
+    int rc = 0;
+    const vit_config *c = &ctx->cfg;
+    const int E = c->embed_dim, F = c->mlp_hidden, rows = n * ctx->tokens, fold = ctx->ln_fold, last = l == c->depth - 1;
+    float **lw = ctx->w + 4 + 12 * l;
+    void **lw16 = ctx->w16 + 4 + 12 * l;
+    float **cs = ctx->fold_cs + 4 + 12 * l, **bf = ctx->fold_b + 4 + 12 * l;
+    const int kind = qkv_as_planes(ctx) ? 2 : 0;
+    if (!fold)
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_planes(s, ctx->x, lw[0], lw[1], ctx->y, 1, rows, E, E, c->eps));
+    OP(VIT_OP_QKV, fold ? vh_launch_linear_planes_norm(s, ctx->qkv, kind, lw16[2], ctx->y, ctx->stats, cs[2], bf[2], c->eps, rows, E, 3 * E, 0)
+                        : vh_launch_linear_planes(s, ctx->qkv, kind, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
+    TRY(attention_reduced(ctx, s, n, NULL));
+    OP(VIT_OP_OUT_PROJ, fold ? vh_launch_linear_planes_resid_norm(s, ctx->x, lw16[4], ctx->attn, lw[5], ctx->x, rows, E, E, ctx->y, NULL, ctx->stats)
+                             : vh_launch_linear_planes(s, ctx->x, 0, lw16[4], ctx->attn, 1, lw[5], rows, E, E, 0, ctx->x));
+    if (!fold)
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_planes(s, ctx->x, lw[6], lw[7], ctx->y, 1, rows, E, E, c->eps));
+    OP(VIT_OP_FC1, fold ? vh_launch_linear_planes_norm(s, ctx->hid, 1, lw16[8], ctx->y, ctx->stats, cs[8], bf[8], c->eps, rows, E, F, 1)
+                        : vh_launch_linear_planes(s, ctx->hid, 1, lw16[8], ctx->y, 1, lw[9], rows, E, F, 1, NULL));
+    OP(VIT_OP_FC2, fold && !last ? vh_launch_linear_planes_resid_norm(s, ctx->x, lw16[10], ctx->hid, lw[11], ctx->x, rows, F, E, ctx->y, NULL, ctx->stats)
+                                 : vh_launch_linear_planes(s, ctx->x, 0, lw16[10], ctx->hid, 1, lw[11], rows, F, E, 0, ctx->x));
+    return 0;
+fail:
+    return rc;
+}
+
+/* F32_FP16X2: the fp32 layer with the four projections on two fp16 parts / three products */
+static int layer_fp16x2(vit_hip_ctx *ctx, vh_stream_t s, int n, int l)
+{
+    int rc = 0;
+    const vit_config *c = &ctx->cfg;
+    const int E = c->embed_dim, F = c->mlp_hidden, T = ctx->tokens, rows = n * T;
+    float **lw = ctx->w + 4 + 12 * l;
+    void **l3 = ctx->w3 + 4 + 12 * l;
+    const float *ws = ctx->w3_scale + 4 + 12 * l;
+    OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
+    OP(VIT_OP_QKV, vh_launch_linear_h2(s, ctx->qkv, l3[2], ws[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+    OP(VIT_OP_ATTENTION, vh_launch_attention_h2(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+    OP(VIT_OP_OUT_PROJ, vh_launch_linear_h2(s, ctx->x, l3[4], ws[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+    OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
+    OP(VIT_OP_FC1, vh_launch_linear_h2(s, ctx->hid, l3[8], ws[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+    OP(VIT_OP_FC2, vh_launch_linear_h2(s, ctx->x, l3[10], ws[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+    return 0;
+fail:
+    return rc;
+}
+
+/* F32, the default: GEMM inputs as exact three-part planes written by LayerNorm, attention and the fc1 epilogue.  ln_fold
+ * here is the LAB VARIANT ($VIT_HIP_LN_FOLD=1, docs/LABBOOK.md R4.6): ctx->y then holds the split of x itself.
+ * *cls_rows is set when the last layer ran on the class-token rows only (opt-in): the final LayerNorm then reads them
+ * compacted at the start of the Q|K|V buffer. */
+static int layer_f32_planes(vit_hip_ctx *ctx, vh_stream_t s, int n, int l, int *cls_rows)
+{
+    int rc = 0;
+    const vit_config *c = &ctx->cfg;
+    const int E = c->embed_dim, F = c->mlp_hidden, T = ctx->tokens, rows = n * T, fold = ctx->ln_fold, last = l == c->depth - 1;
+    float **lw = ctx->w + 4 + 12 * l;
+    void **l3 = ctx->w3 + 4 + 12 * l;
+    float **cs = ctx->fold_cs + 4 + 12 * l, **bf = ctx->fold_b + 4 + 12 * l;
+    /* head_dim 64, T <= 208: Q, K, V too travel as planes (only the probabilities are split inside the attention kernel);
+     * other shapes: the streaming kernel, fp32 rows in, fp32 out (into the idle MLP buffer), then split */
+    const int planes_attn = E == 64 * c->num_heads && T <= 208;
+    if (!fold)
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, c->eps));
+    OP(VIT_OP_QKV, fold ? vh_launch_linear_p3_norm(s, ctx->qkv, planes_attn, l3[2], ctx->y, ctx->stats, cs[2], bf[2], c->eps, rows, E, 3 * E, 0)
+                        : vh_launch_linear_p3(s, ctx->qkv, planes_attn, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+    OP(VIT_OP_ATTENTION, planes_attn ? vh_launch_attention_planes(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads)
+                         : (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc
+                         : vh_launch_split3_rows(s, ctx->hid, ctx->attn, rows, E));
+    if (last && ctx->cls_only_last && T >= 4) {
+        /* Opt-in (vit_hip_set_last_layer_cls_only / $VIT_HIP_LAST_LAYER=cls).  The classifier reads row 0 of every
+         * image only (ViT_seq.c:511), and behind the last attention no operator mixes rows: the output projection,
+         * LayerNorm and MLP of the last layer are evaluated for the n class-token rows instead of n * T, in the
+         * Q|K|V buffer the attention has just released.  Same kernels, same k order: identical logits, bit for
+         * bit; the residual stream of the other rows (vit_hip_read_tokens) is NOT updated by this layer. */
+        char *scratch = (char *)ctx->qkv;
+        float *x_cls = (float *)scratch;
+        char *attn_cls = scratch + align_up((size_t)n * E * 4, 256);
+        char *y_cls = attn_cls + align_up((size_t)n * E * 6, 256);
+        char *hid_cls = y_cls + align_up((size_t)n * E * 6, 256);
+        OP(VIT_OP_OUT_PROJ, (rc = vh_launch_gather_rows(s, ctx->attn, attn_cls, 3 * (E / 32), rows, n, 64, T)) != 0 ? rc :
+                            (rc = vh_launch_gather_rows(s, ctx->x, x_cls, 1, rows, n, 4 * E, T)) != 0 ? rc :
+                            vh_launch_linear_p3(s, x_cls, 0, l3[4], attn_cls, lw[5], n, E, E, 0, x_cls));
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, x_cls, lw[6], lw[7], y_cls, n, E, E, c->eps));
+        OP(VIT_OP_FC1, vh_launch_linear_p3(s, hid_cls, 1, l3[8], y_cls, lw[9], n, E, F, 1, NULL));
+        OP(VIT_OP_FC2, vh_launch_linear_p3(s, x_cls, 0, l3[10], hid_cls, lw[11], n, F, E, 0, x_cls));
+        *cls_rows = 1;
+        return 0;
+    }
+    OP(VIT_OP_OUT_PROJ, fold ? vh_launch_linear_p3_resid_norm(s, ctx->x, l3[4], ctx->attn, lw[5], ctx->x, rows, E, E, ctx->y, ctx->stats)
+                             : vh_launch_linear_p3(s, ctx->x, 0, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+    if (!fold)
+        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, c->eps));
+    OP(VIT_OP_FC1, fold ? vh_launch_linear_p3_norm(s, ctx->hid, 1, l3[8], ctx->y, ctx->stats, cs[8], bf[8], c->eps, rows, E, F, 1)
+                        : vh_launch_linear_p3(s, ctx->hid, 1, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+    OP(VIT_OP_FC2, fold && !last ? vh_launch_linear_p3_resid_norm(s, ctx->x, l3[10], ctx->hid, lw[11], ctx->x, rows, F, E, ctx->y, ctx->stats)
+                                 : vh_launch_linear_p3(s, ctx->x, 0, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+    return 0;
+fail:
+    return rc;
+}
+
+/* F32 with fp32 activation rows ($VIT_HIP_P3=0, $VIT_HIP_GEMM_FP32=native, or shapes the planes cannot take): round 1's
+ * kernels, operands split inside the K loop (pre-split weight planes when built) or the native fp32 MFMA */
+static int layer_f32_rows(vit_hip_ctx *ctx, vh_stream_t s, int n, int l)
+{
+    int rc = 0;
+    const vit_config *c = &ctx->cfg;
+    const int E = c->embed_dim, F = c->mlp_hidden, T = ctx->tokens, rows = n * T;
+    float **lw = ctx->w + 4 + 12 * l;   /* ln1 w,b; in w,b; out w,b; ln2 w,b; fc1 w,b; fc2 w,b */
+    void **l3 = ctx->w3 + 4 + 12 * l;   /* pre-split weight planes, when built */
+    OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
+    OP(VIT_OP_QKV, l3[2] ? vh_launch_linear_w3(s, ctx->qkv, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL)
+                         : vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
+    OP(VIT_OP_ATTENTION, vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
+    OP(VIT_OP_OUT_PROJ, l3[4] ? vh_launch_linear_w3(s, ctx->x, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x)
+                              : vh_launch_linear(s, ctx->x, lw[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
+    OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
+    OP(VIT_OP_FC1, l3[8] ? vh_launch_linear_w3(s, ctx->hid, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL)
+                         : vh_launch_linear(s, ctx->hid, lw[8], ctx->y, lw[9], rows, E, F, 1, NULL));
+    OP(VIT_OP_FC2, l3[10] ? vh_launch_linear_w3(s, ctx->x, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x)
+                          : vh_launch_linear(s, ctx->x, lw[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
+    return 0;
+fail:
+    return rc;
+}
+
+/* patch embedding + class token + position embedding (ViT_seq.c:437-443), in the form the mode's first layer reads */
+static int patch_embedding(vit_hip_ctx *ctx, vh_stream_t s, const float *d_images, int n)
+{
+    int rc = 0;
+    const vit_config *c = &ctx->cfg;
+    const int E = c->embed_dim;
+    float **w = ctx->w;
+    /* ln_fold: y receives the token rows as the first projection's operand -- planes, or MX values with their scales behind
+     * them -- and stats their partial sums (class-token rows included) */
+    char *const y_scales = (char *)ctx->y + align_up((size_t)n * ctx->tokens * E, 256);
+    if (ctx->ln_fold && ctx->precision == VIT_PRECISION_F32)   /* lab variant: the fold on three-part planes */
         OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_planes3_norm(s, d_images, ctx->wconv16, w[2], w[0], w[3], ctx->x, n, c->in_chans,
                                                                   c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes, ctx->y, ctx->stats));
-    else if (fold)
+    else if (ctx->ln_fold)
         OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_planes_norm(s, d_images, ctx->wconv16, w[2], w[0], w[3], ctx->x, n, c->in_chans,
                                                                  c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes, ctx->y,
                                                                  ctx->precision == VIT_PRECISION_FP8_GEMM ? y_scales : NULL, ctx->stats));
@@ -827,215 +1018,43 @@ int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float
     else
         OP(VIT_OP_PATCH_EMBED, vh_launch_patch_embed_ws(s, d_images, w[1], w[2], w[0], w[3], ctx->x, n, c->in_chans,
                                                         c->img_size, c->patch_size, E, ctx->hid, ctx->ws_bytes));
+    return 0;
+fail:
+    return rc;
+}
 
-    const int mode = ctx->precision;
-    const float *final_x = ctx->x;          /* what the final LayerNorm reads: row i * final_stride is image i's class token */
-    long final_stride = (long)T * E;
-    for (int l = 0; l < c->depth && mode == VIT_PRECISION_FP8_GEMM; ++l) {
-        /* block-scaled fp8 GEMM operands: y, attn and hid hold MX tensors (values, then the scales, in the same
-         * allocations); qkv and the residual stream stay fp32; attention as in the other reduced modes */
-        float **lw = w + 4 + 12 * l;
-        void **l8 = ctx->w8 + 4 + 12 * l, **l8s = ctx->w8s + 4 + 12 * l;
-        char *ys = (char *)ctx->y + align_up((size_t)rows * E, 256), *as_ = (char *)ctx->attn + align_up((size_t)rows * E, 256);
-        char *hs = (char *)ctx->hid + align_up((size_t)rows * F, 256);
-        if (fold) {
-            /* LayerNorms folded (csrc/norm_fold.h): ctx->y / ys = MX(x) and ctx->stats come from the patch embedding or the
-             * previous layer's fc2; QKV and fc1 apply the row terms in their epilogues; out-proj and fc2 refresh both */
-            const float *cs_in = ctx->fold_cs[4 + 12 * l + 2], *bf_in = ctx->fold_b[4 + 12 * l + 2];
-            const float *cs_f1 = ctx->fold_cs[4 + 12 * l + 8], *bf_f1 = ctx->fold_b[4 + 12 * l + 8];
-            const int planes_qkv = (E == 64 * c->num_heads && T <= 208) || (E == 80 * c->num_heads && T <= 272);
-            OP(VIT_OP_QKV, vh_launch_linear_mx_norm(s, ctx->qkv, NULL, planes_qkv ? 2 : 0, l8[2], l8s[2], ctx->y, ys, ctx->stats, cs_in,
-                                                    bf_in, c->eps, rows, E, 3 * E, 0));
-            if (E == 64 * c->num_heads && T <= 208)
-                OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16_mx(s, ctx->qkv, ctx->attn, as_, n, T, E, c->num_heads));
-            else if (planes_qkv)
-                OP(VIT_OP_ATTENTION, (c->num_heads & 1) == 0
-                       ? vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, as_, 2, n, T, E, c->num_heads)
-                       : (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                         vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
+int vit_hip_forward_device(vit_hip_ctx *ctx, const float *d_images, int n, float *d_logits,
+                           float *d_probs, vh_stream_t stream)
+{
+    int rc = 0;
+    if (!ctx || !d_images || n <= 0 || n > ctx->max_batch)
+        return 1;
+    TRY(vh_set_device(ctx->device));   /* the current device is per host thread */
+    const vit_config *c = &ctx->cfg;
+    const int E = c->embed_dim, T = ctx->tokens, NC = c->num_classes;
+    vh_stream_t s = stream ? stream : ctx->stream;
+
+    TRY(patch_embedding(ctx, s, d_images, n));
+    int cls_rows = 0;   /* the last layer ran on the class-token rows only (opt-in, fp32 path on planes) */
+    for (int l = 0; l < c->depth; ++l) {
+        switch (ctx->precision) {
+        case VIT_PRECISION_FP8_GEMM: TRY(layer_fp8(ctx, s, n, l)); break;
+        case VIT_PRECISION_BF16_GEMM: TRY(layer_bf16(ctx, s, n, l)); break;
+        case VIT_PRECISION_F32_FP16X2: TRY(layer_fp16x2(ctx, s, n, l)); break;
+        default:
+            if (ctx->use_p3)
+                TRY(layer_f32_planes(ctx, s, n, l, &cls_rows));
             else
-                OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                                     vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
-            OP(VIT_OP_OUT_PROJ, vh_launch_linear_mx_resid_norm(s, ctx->x, l8[4], l8s[4], ctx->attn, as_, lw[5], ctx->x, rows, E, E,
-                                                               ctx->y, ys, ctx->stats));
-            OP(VIT_OP_FC1, vh_launch_linear_mx_norm(s, ctx->hid, hs, 1, l8[8], l8s[8], ctx->y, ys, ctx->stats, cs_f1, bf_f1, c->eps,
-                                                    rows, E, F, 1));
-            if (l == c->depth - 1)   /* nothing reads the operand behind the last layer: the final LayerNorm takes the fp32 rows */
-                OP(VIT_OP_FC2, vh_launch_linear_mx(s, ctx->x, NULL, l8[10], l8s[10], ctx->hid, hs, lw[11], rows, F, E, 0, ctx->x));
-            else
-                OP(VIT_OP_FC2, vh_launch_linear_mx_resid_norm(s, ctx->x, l8[10], l8s[10], ctx->hid, hs, lw[11], ctx->x, rows, F, E,
-                                                              ctx->y, ys, ctx->stats));
-            continue;
+                TRY(layer_f32_rows(ctx, s, n, l));
         }
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[0], lw[1], ctx->y, ys, rows, E, E, c->eps));
-        /* attention on fp16-rounded operands.  head_dim 64 / T <= 208: the projection's epilogue rounds Q|K|V to fp16
-         * planes and the attention kernel writes the MX tensor; other shapes: fp32 out (into the idle MLP buffer),
-         * then quantised (one timed operator) */
-        if (E == 64 * c->num_heads && T <= 208) {
-            OP(VIT_OP_QKV, vh_launch_linear_mx_planes_f16(s, ctx->qkv, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E));
-            OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16_mx(s, ctx->qkv, ctx->attn, as_, n, T, E, c->num_heads));
-        } else if (E == 80 * c->num_heads && T <= 272) {   /* ViT-H/14: fp16 planes in, K and V resident in LDS, fp32 rows out */
-            OP(VIT_OP_QKV, vh_launch_linear_mx_planes_f16(s, ctx->qkv, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E));
-            OP(VIT_OP_ATTENTION, (c->num_heads & 1) == 0
-                   ? vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, as_, 2, n, T, E, c->num_heads)   /* writes the MX tensor itself */
-                   : (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                     vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
-        } else {
-            OP(VIT_OP_QKV, vh_launch_linear_mx(s, ctx->qkv, NULL, l8[2], l8s[2], ctx->y, ys, lw[3], rows, E, 3 * E, 0, NULL));
-            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                                 vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, as_, rows, E));
-        }
-        OP(VIT_OP_OUT_PROJ, vh_launch_linear_mx(s, ctx->x, NULL, l8[4], l8s[4], ctx->attn, as_, lw[5], rows, E, E, 0, ctx->x));
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_mx(s, ctx->x, lw[6], lw[7], ctx->y, ys, rows, E, E, c->eps));
-        OP(VIT_OP_FC1, vh_launch_linear_mx(s, ctx->hid, hs, l8[8], l8s[8], ctx->y, ys, lw[9], rows, E, F, 1, NULL));
-        OP(VIT_OP_FC2, vh_launch_linear_mx(s, ctx->x, NULL, l8[10], l8s[10], ctx->hid, hs, lw[11], rows, F, E, 0, ctx->x));
-    }
-    for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32_FP16X2; ++l) {
-        /* the fp32 layer with the four projections on two fp16 parts / three products */
-        float **lw = w + 4 + 12 * l;
-        void **l3 = ctx->w3 + 4 + 12 * l;
-        const float *ws = ctx->w3_scale + 4 + 12 * l;
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
-        OP(VIT_OP_QKV, vh_launch_linear_h2(s, ctx->qkv, l3[2], ws[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
-        OP(VIT_OP_ATTENTION, vh_launch_attention_h2(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-        OP(VIT_OP_OUT_PROJ, vh_launch_linear_h2(s, ctx->x, l3[4], ws[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
-        OP(VIT_OP_FC1, vh_launch_linear_h2(s, ctx->hid, l3[8], ws[8], ctx->y, lw[9], rows, E, F, 1, NULL));
-        OP(VIT_OP_FC2, vh_launch_linear_h2(s, ctx->x, l3[10], ws[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
-    }
-    for (int l = 0; l < c->depth && mode == VIT_PRECISION_BF16_GEMM; ++l) {
-        /* bf16 GEMM operands as one-part planes [K/32][1][rows][32], written by their producers; the same
-         * kernel as the fp32 path with one product per block (gemm_p3.hip, NPL = 1) */
-        float **lw = w + 4 + 12 * l;
-        void **lw16 = ctx->w16 + 4 + 12 * l;
-        if (fold) {
-            /* LayerNorms folded (csrc/norm_fold.h): ctx->y = bf16(x) planes and ctx->stats come from the patch embedding or the
-             * previous layer's fc2; QKV and fc1 apply the row terms in their epilogues; out-proj and fc2 refresh both */
-            const float *cs_in = ctx->fold_cs[4 + 12 * l + 2], *bf_in = ctx->fold_b[4 + 12 * l + 2];
-            const float *cs_f1 = ctx->fold_cs[4 + 12 * l + 8], *bf_f1 = ctx->fold_b[4 + 12 * l + 8];
-            const int planes_qkv = (E == 64 * c->num_heads && T <= 208) || (E == 80 * c->num_heads && T <= 272);
-            OP(VIT_OP_QKV, vh_launch_linear_planes_norm(s, ctx->qkv, planes_qkv ? 2 : 0, lw16[2], ctx->y, ctx->stats, cs_in, bf_in, c->eps,
-                                                        rows, E, 3 * E, 0));
-            if (E == 64 * c->num_heads && T <= 208)
-                OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16(s, ctx->qkv, ctx->attn, 1, n, T, E, c->num_heads));
-            else if (planes_qkv)
-                OP(VIT_OP_ATTENTION, (c->num_heads & 1) == 0
-                       ? vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, NULL, 1, n, T, E, c->num_heads)
-                       : (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                         vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
-            else
-                OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                                     vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
-            OP(VIT_OP_OUT_PROJ, vh_launch_linear_planes_resid_norm(s, ctx->x, lw16[4], ctx->attn, lw[5], ctx->x, rows, E, E, ctx->y, NULL,
-                                                                   ctx->stats));
-            OP(VIT_OP_FC1, vh_launch_linear_planes_norm(s, ctx->hid, 1, lw16[8], ctx->y, ctx->stats, cs_f1, bf_f1, c->eps, rows, E, F, 1));
-            if (l == c->depth - 1)   /* nothing reads the operand behind the last layer: the final LayerNorm takes the fp32 rows */
-                OP(VIT_OP_FC2, vh_launch_linear_planes(s, ctx->x, 0, lw16[10], ctx->hid, 1, lw[11], rows, F, E, 0, ctx->x));
-            else
-                OP(VIT_OP_FC2, vh_launch_linear_planes_resid_norm(s, ctx->x, lw16[10], ctx->hid, lw[11], ctx->x, rows, F, E, ctx->y, NULL,
-                                                                  ctx->stats));
-            continue;
-        }
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_planes(s, ctx->x, lw[0], lw[1], ctx->y, 1, rows, E, E, c->eps));
-        if (E == 64 * c->num_heads && T <= 208) {   /* Q|K|V rounded to fp16 planes by the projection's epilogue */
-            OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 2, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
-            OP(VIT_OP_ATTENTION, vh_launch_attention_planes_f16(s, ctx->qkv, ctx->attn, 1, n, T, E, c->num_heads));
-        } else if (E == 80 * c->num_heads && T <= 272) {   /* ViT-H/14: fp16 planes in, K and V resident in LDS, fp32 rows out */
-            OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 2, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
-            OP(VIT_OP_ATTENTION, (c->num_heads & 1) == 0
-                   ? vh_launch_attention_planes_f16_hd80_operand(s, ctx->qkv, ctx->attn, NULL, 1, n, T, E, c->num_heads)  /* writes the planes itself */
-                   : (rc = vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                     vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
-        } else {   /* other shapes of the streaming attention kernel: fp32 output (into the idle MLP buffer), then rounded into planes */
-            OP(VIT_OP_QKV, vh_launch_linear_planes(s, ctx->qkv, 0, lw16[2], ctx->y, 1, lw[3], rows, E, 3 * E, 0, NULL));
-            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                                 vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
-        }
-        OP(VIT_OP_OUT_PROJ, vh_launch_linear_planes(s, ctx->x, 0, lw16[4], ctx->attn, 1, lw[5], rows, E, E, 0, ctx->x));
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_planes(s, ctx->x, lw[6], lw[7], ctx->y, 1, rows, E, E, c->eps));
-        OP(VIT_OP_FC1, vh_launch_linear_planes(s, ctx->hid, 1, lw16[8], ctx->y, 1, lw[9], rows, E, F, 1, NULL));
-        OP(VIT_OP_FC2, vh_launch_linear_planes(s, ctx->x, 0, lw16[10], ctx->hid, 1, lw[11], rows, F, E, 0, ctx->x));
-    }
-    for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32 && ctx->use_p3; ++l) {
-        /* GEMM inputs as pre-split planes: LayerNorm, attention and the fc1 epilogue write them */
-        float **lw = w + 4 + 12 * l;
-        void **l3 = ctx->w3 + 4 + 12 * l;
-        if (fold) {
-            /* LAB VARIANT ($VIT_HIP_LN_FOLD=1): the reduced modes' LayerNorm fold (csrc/norm_fold.h) on the exact three-part
-             * planes -- ctx->y holds the split of x itself, QKV and fc1 apply the row terms */
-            const float *cs_in = ctx->fold_cs[4 + 12 * l + 2], *bf_in = ctx->fold_b[4 + 12 * l + 2];
-            const float *cs_f1 = ctx->fold_cs[4 + 12 * l + 8], *bf_f1 = ctx->fold_b[4 + 12 * l + 8];
-            if (E == 64 * c->num_heads && T <= 208) {
-                OP(VIT_OP_QKV, vh_launch_linear_p3_norm(s, ctx->qkv, 1, l3[2], ctx->y, ctx->stats, cs_in, bf_in, c->eps, rows, E, 3 * E, 0));
-                OP(VIT_OP_ATTENTION, vh_launch_attention_planes(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-            } else {
-                OP(VIT_OP_QKV, vh_launch_linear_p3_norm(s, ctx->qkv, 0, l3[2], ctx->y, ctx->stats, cs_in, bf_in, c->eps, rows, E, 3 * E, 0));
-                OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                                     vh_launch_split3_rows(s, ctx->hid, ctx->attn, rows, E));
-            }
-            OP(VIT_OP_OUT_PROJ, vh_launch_linear_p3_resid_norm(s, ctx->x, l3[4], ctx->attn, lw[5], ctx->x, rows, E, E, ctx->y, ctx->stats));
-            OP(VIT_OP_FC1, vh_launch_linear_p3_norm(s, ctx->hid, 1, l3[8], ctx->y, ctx->stats, cs_f1, bf_f1, c->eps, rows, E, F, 1));
-            if (l == c->depth - 1)
-                OP(VIT_OP_FC2, vh_launch_linear_p3(s, ctx->x, 0, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
-            else
-                OP(VIT_OP_FC2, vh_launch_linear_p3_resid_norm(s, ctx->x, l3[10], ctx->hid, lw[11], ctx->x, rows, F, E, ctx->y, ctx->stats));
-            continue;
-        }
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, c->eps));
-        if (E == 64 * c->num_heads && T <= 208) {
-            /* Q, K, V too travel as planes: only the probabilities are split inside the attention kernel */
-            OP(VIT_OP_QKV, vh_launch_linear_p3(s, ctx->qkv, 1, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
-            OP(VIT_OP_ATTENTION, vh_launch_attention_planes(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-        } else {   /* shapes of the streaming attention kernel: fp32 rows in, fp32 out (into the idle MLP buffer), then split */
-            OP(VIT_OP_QKV, vh_launch_linear_p3(s, ctx->qkv, 0, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
-            OP(VIT_OP_ATTENTION, (rc = vh_launch_attention(s, ctx->qkv, ctx->hid, n, T, E, c->num_heads)) != 0 ? rc :
-                                 vh_launch_split3_rows(s, ctx->hid, ctx->attn, rows, E));
-        }
-        if (l == c->depth - 1 && ctx->cls_only_last && T >= 4) {
-            /* Opt-in (vit_hip_set_last_layer_cls_only / $VIT_HIP_LAST_LAYER=cls).  The classifier reads row 0 of every
-             * image only (ViT_seq.c:511), and behind the last attention no operator mixes rows: the output projection,
-             * LayerNorm and MLP of the last layer are evaluated for the n class-token rows instead of n * T, in the
-             * Q|K|V buffer the attention has just released.  Same kernels, same k order: identical logits, bit for
-             * bit; the residual stream of the other rows (vit_hip_read_tokens) is NOT updated by this layer. */
-            char *scratch = (char *)ctx->qkv;
-            float *x_cls = (float *)scratch;
-            char *attn_cls = scratch + align_up((size_t)n * E * 4, 256);
-            char *y_cls = attn_cls + align_up((size_t)n * E * 6, 256);
-            char *hid_cls = y_cls + align_up((size_t)n * E * 6, 256);
-            OP(VIT_OP_OUT_PROJ, (rc = vh_launch_gather_rows(s, ctx->attn, attn_cls, 3 * (E / 32), rows, n, 64, T)) != 0 ? rc :
-                                (rc = vh_launch_gather_rows(s, ctx->x, x_cls, 1, rows, n, 4 * E, T)) != 0 ? rc :
-                                vh_launch_linear_p3(s, x_cls, 0, l3[4], attn_cls, lw[5], n, E, E, 0, x_cls));
-            OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, x_cls, lw[6], lw[7], y_cls, n, E, E, c->eps));
-            OP(VIT_OP_FC1, vh_launch_linear_p3(s, hid_cls, 1, l3[8], y_cls, lw[9], n, E, F, 1, NULL));
-            OP(VIT_OP_FC2, vh_launch_linear_p3(s, x_cls, 0, l3[10], hid_cls, lw[11], n, F, E, 0, x_cls));
-            final_x = x_cls;
-            final_stride = E;
-            break;
-        }
-        OP(VIT_OP_OUT_PROJ, vh_launch_linear_p3(s, ctx->x, 0, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm_p3(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, c->eps));
-        OP(VIT_OP_FC1, vh_launch_linear_p3(s, ctx->hid, 1, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL));
-        OP(VIT_OP_FC2, vh_launch_linear_p3(s, ctx->x, 0, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
-    }
-    for (int l = 0; l < c->depth && mode == VIT_PRECISION_F32 && !ctx->use_p3; ++l) {
-        float **lw = w + 4 + 12 * l; /* ln1 w,b; in w,b; out w,b; ln2 w,b; fc1 w,b; fc2 w,b */
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[0], lw[1], ctx->y, rows, E, E, E, c->eps));
-        void **l3 = ctx->w3 + 4 + 12 * l;   /* pre-split weight planes, when built */
-        OP(VIT_OP_QKV, l3[2] ? vh_launch_linear_w3(s, ctx->qkv, l3[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL)
-                             : vh_launch_linear(s, ctx->qkv, lw[2], ctx->y, lw[3], rows, E, 3 * E, 0, NULL));
-        OP(VIT_OP_ATTENTION, vh_launch_attention(s, ctx->qkv, ctx->attn, n, T, E, c->num_heads));
-        OP(VIT_OP_OUT_PROJ, l3[4] ? vh_launch_linear_w3(s, ctx->x, l3[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x)
-                                  : vh_launch_linear(s, ctx->x, lw[4], ctx->attn, lw[5], rows, E, E, 0, ctx->x));
-        OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, ctx->x, lw[6], lw[7], ctx->y, rows, E, E, E, c->eps));
-        OP(VIT_OP_FC1, l3[8] ? vh_launch_linear_w3(s, ctx->hid, l3[8], ctx->y, lw[9], rows, E, F, 1, NULL)
-                             : vh_launch_linear(s, ctx->hid, lw[8], ctx->y, lw[9], rows, E, F, 1, NULL));
-        OP(VIT_OP_FC2, l3[10] ? vh_launch_linear_w3(s, ctx->x, l3[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x)
-                              : vh_launch_linear(s, ctx->x, lw[10], ctx->hid, lw[11], rows, F, E, 0, ctx->x));
     }
 
-    /* final LayerNorm on the class-token rows, classifier, softmax (ViT_seq.c:506-515) */
-    float **tw = w + 4 + 12 * c->depth;
+    /* final LayerNorm on the class-token rows -- row i * stride of the residual stream, or compacted at the start of the
+     * Q|K|V buffer -- classifier, softmax (ViT_seq.c:506-515) */
+    float **tw = ctx->w + 4 + 12 * c->depth;
     float *logits = d_logits ? d_logits : ctx->d_logits;
+    const float *final_x = cls_rows ? (const float *)ctx->qkv : ctx->x;
+    const long final_stride = cls_rows ? (long)E : (long)T * E;
     OP(VIT_OP_LAYER_NORM, vh_launch_layer_norm(s, final_x, tw[0], tw[1], ctx->cls, n, E, final_stride, E, c->eps));
     OP(VIT_OP_HEAD, vh_launch_linear(s, logits, tw[2], ctx->cls, tw[3], n, E, NC, 0, NULL));
     if (d_probs)
