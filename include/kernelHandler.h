@@ -265,6 +265,13 @@ int vh_launch_absmax(vh_stream_t s, const float *input, size_t count, float *ama
  * statement both are checked against byte for byte).  Scales are per block and computed where the tensor is
  * produced: no calibration pass. */
 int vh_launch_quantize_mx_rows(vh_stream_t s, const float *input, void *values, void *scales, int rows, int cols);
+/* An ACTIVATION tensor [rows][cols] as MX: values as above, scale bytes as [ceil(cols/512)][4][rows][4] -- K steps in
+ * groups of four, lane group, row, K step within the group -- so that the GEMM's lane takes its scales of four K steps
+ * with one dword load (vh_mx_act_scale_bytes(rows, cols) bytes, 4-byte aligned).  Every producer of a GEMM input writes
+ * this form (vh_launch_layer_norm_mx, the fc1 / attention epilogues, the folded-LayerNorm producers); vh_launch_linear_mx*
+ * take it for `input_scales`.  Weights keep [cols/128][4][rows] (vh_launch_quantize_mx_rows). */
+int vh_launch_quantize_mx_act(vh_stream_t s, const float *input, void *values, void *scales, int rows, int cols);
+size_t vh_mx_act_scale_bytes(int rows, int cols);
 /* vh_launch_layer_norm writing its result as an MX tensor (embed_dim % 128 == 0) */
 int vh_launch_layer_norm_mx(vh_stream_t s, const float *input, const float *weight, const float *bias,
                             void *out_values, void *out_scales, int rows, int embed_dim, long in_row_stride, double eps);

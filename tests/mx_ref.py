@@ -18,6 +18,30 @@ import fp8_ref
 
 GROUP_OF_BLOCK = [0, 2, 1, 3]          # block b is stored in lane-group slot 2 (b & 1) + (b >> 1)
 
+# ACTIVATION tensors carry the same scale bytes in another order (csrc/vit_kernels.h mx_act_scale_index):
+#     act_scales[ceil(K/512)][4 lane groups][rows][4]   -- K steps in groups of four; the GEMM's lane takes its scales
+# of four K steps with one dword load.  Bytes of K steps beyond K/128 in the last group are unspecified.
+
+
+def act_scale_bytes(rows: int, cols: int) -> int:
+    return ((cols // 128 + 3) // 4) * 16 * rows
+
+
+def to_act_layout(scales: np.ndarray) -> np.ndarray:
+    """scales[K/128][4][rows] (the weights' order, what quantize() returns) -> flat uint8 in the activation order"""
+    ks, _, rows = scales.shape
+    out = np.zeros(((ks + 3) // 4, 4, rows, 4), dtype=np.uint8)
+    for k in range(ks):
+        out[k >> 2, :, :, k & 3] = scales[k]
+    return out.ravel()
+
+
+def from_act_layout(raw: np.ndarray, rows: int, cols: int) -> np.ndarray:
+    """flat uint8 in the activation order -> scales[K/128][4][rows] (padding bytes dropped)"""
+    ks = cols // 128
+    a = np.asarray(raw, dtype=np.uint8)[:act_scale_bytes(rows, cols)].reshape((ks + 3) // 4, 4, rows, 4)
+    return np.stack([a[k >> 2, :, :, k & 3] for k in range(ks)])
+
 
 def quantize(x: np.ndarray):
     """fp32 [rows][cols] -> (values uint8 [cols/128][rows][128], scales uint8 [cols/128][4][rows])."""

@@ -142,14 +142,20 @@ def test_bf16_consumer_applies_the_folded_layernorm(pkg, device, oracle, weights
     assert (np.abs(got[rows] - ref).max(1) <= (2.0 ** -7 * amp + 2.0 ** -8) * max(1.0, np.abs(ref).max())).all()
 
 
-def _mx_dev(pkg, x):
-    """fp32 rows -> (values, scales) device buffers through the library's quantiser; also their numpy dequantisation"""
+def _act_buf(pkg, rows, cols):
+    return pkg.DeviceBuffer(mx_ref.act_scale_bytes(rows, cols) // 4 + 4)
+
+
+def _mx_dev(pkg, x, act):
+    """fp32 rows -> (values, scales) device buffers through the library's quantiser -- act: an activation tensor (a GEMM's A
+    operand, scale bytes in the activation order), else a weight matrix -- and their numpy dequantisation"""
     M, K = x.shape
     d_x = _dev(pkg, x)
-    d_v, d_s = pkg.DeviceBuffer(M * K // 4), pkg.DeviceBuffer((M * K // 32 + 3) // 4 + 4)
-    _launch(pkg, "vh_launch_quantize_mx_rows", None, d_x.ptr, d_v.ptr, d_s.ptr, M, K)
+    d_v, d_s = pkg.DeviceBuffer(M * K // 4), _act_buf(pkg, M, K) if act else pkg.DeviceBuffer((M * K // 32 + 3) // 4 + 4)
+    _launch(pkg, "vh_launch_quantize_mx_act" if act else "vh_launch_quantize_mx_rows", None, d_x.ptr, d_v.ptr, d_s.ptr, M, K)
     v = d_v.to_numpy().view(np.uint8)[:M * K].reshape(K // 128, M, 128)
-    s = d_s.to_numpy().view(np.uint8)[:M * K // 32].reshape(K // 128, 4, M)
+    raw = d_s.to_numpy().view(np.uint8)
+    s = mx_ref.from_act_layout(raw, M, K) if act else raw[:M * K // 32].reshape(K // 128, 4, M)
     return d_v, d_s, mx_ref.dequantize(v, s)
 
 
@@ -159,11 +165,11 @@ def test_mx_producer_leaves_rows_operand_and_partial_sums(pkg, device, oracle, M
     w = oracle.synth_fill(N * K, 821 + N, 0.04, 0.0).reshape(N, K)
     b = oracle.synth_fill(N, 822, 0.1, 0.0)
     r = _residual_rows(oracle, M, N, 823)
-    d_av, d_as, _ = _mx_dev(pkg, a)
-    d_wv, d_ws, _ = _mx_dev(pkg, w)
+    d_av, d_as, _ = _mx_dev(pkg, a, True)
+    d_wv, d_ws, _ = _mx_dev(pkg, w, False)
     d_b, d_plain, d_x = _dev(pkg, b), _dev(pkg, r), _dev(pkg, r)
     _launch(pkg, "vh_launch_linear_mx", None, d_plain.ptr, None, d_wv.ptr, d_ws.ptr, d_av.ptr, d_as.ptr, d_b.ptr, M, K, N, 0, d_plain.ptr)
-    d_ov, d_os = pkg.DeviceBuffer(M * N // 4), pkg.DeviceBuffer((M * N // 32 + 3) // 4 + 4)
+    d_ov, d_os = pkg.DeviceBuffer(M * N // 4), _act_buf(pkg, M, N)
     d_st = pkg.DeviceBuffer((N // 128) * M * 2)
     _launch(pkg, "vh_launch_linear_mx_resid_norm", None, d_x.ptr, d_wv.ptr, d_ws.ptr, d_av.ptr, d_as.ptr, d_b.ptr, d_x.ptr, M, K, N,
             d_ov.ptr, d_os.ptr, d_st.ptr)
@@ -171,7 +177,7 @@ def test_mx_producer_leaves_rows_operand_and_partial_sums(pkg, device, oracle, M
     assert np.array_equal(x, d_plain.to_numpy((M, N)))
     qv, qs = mx_ref.quantize(x)                                           # the operand: the numpy quantiser, byte for byte
     assert np.array_equal(d_ov.to_numpy().view(np.uint8)[:M * N].reshape(N // 128, M, 128), qv)
-    assert np.array_equal(d_os.to_numpy().view(np.uint8)[:M * N // 32].reshape(N // 128, 4, M), qs)
+    assert np.array_equal(mx_ref.from_act_layout(d_os.to_numpy().view(np.uint8), M, N), qs)
     st = d_st.to_numpy((N // 128, M, 2))
     x64 = x.astype(np.float64).reshape(M, N // 128, 128)
     assert np.abs(st[:, :, 0].T - x64.sum(2)).max() <= 1e-5 * max(1.0, np.abs(x64).sum(2).max())
@@ -186,11 +192,11 @@ def test_mx_consumer_applies_the_folded_layernorm(pkg, device, oracle, M, N, gel
     beta = oracle.synth_fill(K, 832, 0.2, 0.0)
     w = oracle.synth_fill(N * K, 833 + N, 0.04, 0.0).reshape(N, K)
     b = oracle.synth_fill(N, 834, 0.1, 0.0)
-    d_xv, d_xs, xq = _mx_dev(pkg, x)
+    d_xv, d_xs, xq = _mx_dev(pkg, x, True)
     xg = x.reshape(M, K // 128, 128)
     stats = np.stack([xg.sum(2, dtype=np.float32), (xg * xg).sum(2, dtype=np.float32)], axis=2).transpose(1, 0, 2)
     d_st = _dev(pkg, stats)
-    d_wv, d_wsc, wq = _mx_dev(pkg, (w * gamma[None, :]).astype(np.float32))
+    d_wv, d_wsc, wq = _mx_dev(pkg, (w * gamma[None, :]).astype(np.float32), False)
     d_w, d_b, d_be = _dev(pkg, w), _dev(pkg, b), _dev(pkg, beta)
     d_cs, d_bf = pkg.DeviceBuffer(N), pkg.DeviceBuffer(N)
     _launch(pkg, "vh_launch_colsum_operand", None, d_wv.ptr, d_wsc.ptr, d_cs.ptr, N, K)
@@ -198,7 +204,7 @@ def test_mx_consumer_applies_the_folded_layernorm(pkg, device, oracle, M, N, gel
     cs, bf = d_cs.to_numpy(), d_bf.to_numpy()
     assert np.abs(cs - wq.astype(np.float64).sum(1)).max() <= 1e-6 * np.abs(wq).sum(1).max()     # of the DEQUANTISED weights
     if kind == 1:
-        d_o, d_os = pkg.DeviceBuffer(M * N // 4), pkg.DeviceBuffer((M * N // 32 + 3) // 4 + 4)
+        d_o, d_os = pkg.DeviceBuffer(M * N // 4), _act_buf(pkg, M, N)
     elif kind == 2:
         d_o, d_os = pkg.DeviceBuffer((M * N + 1) // 2), None
     else:
@@ -211,7 +217,7 @@ def test_mx_consumer_applies_the_folded_layernorm(pkg, device, oracle, M, N, gel
         want = _gelu64(want)
     if kind == 1:
         got = mx_ref.dequantize(d_o.to_numpy().view(np.uint8)[:M * N].reshape(N // 128, M, 128),
-                                d_os.to_numpy().view(np.uint8)[:M * N // 32].reshape(N // 128, 4, M))
+                                mx_ref.from_act_layout(d_os.to_numpy().view(np.uint8), M, N))
         tol = 2.0 ** -3 * np.abs(want).max()          # one e4m3 rounding (3 significand bits, block-scaled) + the format-matched GELU
     else:
         # v_mfma_scale_f32_16x16x128_f8f6f4 sums the 128 products of an instruction in a fixed-point frame hung on the largest
@@ -257,7 +263,7 @@ def test_patch_embedding_leaves_the_first_operand_and_sums_for_every_token_row(p
             d_ws.ptr, need)
     R = n * T
     d_op = pkg.DeviceBuffer(R * E // 4 if mx else (R * E + 1) // 2)
-    d_os = pkg.DeviceBuffer((R * E // 32 + 3) // 4 + 4) if mx else None
+    d_os = _act_buf(pkg, R, E) if mx else None
     d_st = pkg.DeviceBuffer((E // 128) * R * 2)
     _launch(pkg, "vh_launch_patch_embed_planes_norm", None, d[0].ptr, d_wp.ptr, d[2].ptr, d[3].ptr, d[4].ptr, d_tok.ptr, n, 3, 224, P, E,
             d_ws.ptr, need, d_op.ptr, d_os.ptr if mx else None, d_st.ptr)
@@ -266,7 +272,7 @@ def test_patch_embedding_leaves_the_first_operand_and_sums_for_every_token_row(p
     if mx:
         qv, qs = mx_ref.quantize(x)
         assert np.array_equal(d_op.to_numpy().view(np.uint8)[:R * E].reshape(E // 128, R, 128), qv)
-        assert np.array_equal(d_os.to_numpy().view(np.uint8)[:R * E // 32].reshape(E // 128, 4, R), qs)
+        assert np.array_equal(mx_ref.from_act_layout(d_os.to_numpy().view(np.uint8), R, E), qs)
     else:
         assert np.array_equal(_planes1_to_f32(d_op, R, E), _bf16_rne(x))
     st = d_st.to_numpy((E // 128, R, 2))

@@ -32,11 +32,23 @@ def _launch(pkg, name, *args):
     assert L.vh_device_sync() == 0, L.vh_last_error().decode()
 
 
-def _quantize_gpu(pkg, x):
+def _act_buf(pkg, rows, cols):
+    """device buffer for the scale bytes of an ACTIVATION MX tensor (mx_ref.act_scale_bytes)"""
+    assert pkg.lib().vh_mx_act_scale_bytes(rows, cols) == mx_ref.act_scale_bytes(rows, cols)
+    return pkg.DeviceBuffer(mx_ref.act_scale_bytes(rows, cols) // 4 + 4)
+
+
+def _act_scales(buf, rows, cols):
+    """scale bytes of an activation MX tensor, back in the order of mx_ref.quantize ([K/128][4][rows])"""
+    return mx_ref.from_act_layout(buf.to_numpy().view(np.uint8), rows, cols)
+
+
+def _quantize_gpu(pkg, x, act=False):
+    """act: an activation tensor (a GEMM's A operand; scale bytes in the activation order), else a weight matrix"""
     rows, cols = x.shape
     d_x = _dev(pkg, x)
-    d_v, d_s = pkg.DeviceBuffer(rows * cols // 4 + 4), pkg.DeviceBuffer(rows * cols // 128 + 4)
-    _launch(pkg, "vh_launch_quantize_mx_rows", None, d_x.ptr, d_v.ptr, d_s.ptr, rows, cols)
+    d_v, d_s = pkg.DeviceBuffer(rows * cols // 4 + 4), _act_buf(pkg, rows, cols) if act else pkg.DeviceBuffer(rows * cols // 128 + 4)
+    _launch(pkg, "vh_launch_quantize_mx_act" if act else "vh_launch_quantize_mx_rows", None, d_x.ptr, d_v.ptr, d_s.ptr, rows, cols)
     return d_v, d_s
 
 
@@ -53,6 +65,9 @@ def test_quantize_mx_rows_is_the_numpy_statement_byte_for_byte(pkg, device, orac
     assert np.array_equal(got_s, want_s)
     zero = (want_v & 0x7f) == 0                       # signed zeros: compare magnitudes
     assert np.array_equal(got_v[~zero], want_v[~zero]) and np.array_equal(got_v[zero] & 0x7f, want_v[zero] & 0x7f)
+    d_va, d_sa = _quantize_gpu(pkg, x, act=True)          # the activation form: same values, the scale bytes regrouped
+    assert np.array_equal(_bytes(d_va, rows * cols).reshape(cols // 128, rows, 128), got_v)
+    assert np.array_equal(_act_scales(d_sa, rows, cols), want_s)
     back = mx_ref.dequantize(got_v, got_s)
     blocks = np.abs(x.reshape(rows, cols // 32, 32))
     assert (np.abs(back - x).reshape(rows, cols // 32, 32) <= 2.0 ** -3 * blocks.max(axis=2, keepdims=True) + 1e-37).all()
@@ -76,7 +91,7 @@ def test_linear_mx_vs_float64_products_of_the_dequantised_operands(pkg, device, 
     w = oracle.synth_fill(N * K, 801 + N, 0.04, 0.0).reshape(N, K)
     b = oracle.synth_fill(N, 802, 0.1, 0.0)
     r = oracle.synth_fill(M * N, 803, 1.0, 0.0).reshape(M, N)
-    d_xv, d_xs = _quantize_gpu(pkg, x)
+    d_xv, d_xs = _quantize_gpu(pkg, x, act=True)
     d_wv, d_ws = _quantize_gpu(pkg, w)
     xq = mx_ref.dequantize(*mx_ref.quantize(x))
     wq = mx_ref.dequantize(*mx_ref.quantize(w))
@@ -89,10 +104,10 @@ def test_linear_mx_vs_float64_products_of_the_dequantised_operands(pkg, device, 
     if resid:
         want = r[rows] + want
     if mx_out:
-        d_ov, d_os = pkg.DeviceBuffer(M * N // 4 + 4), pkg.DeviceBuffer(M * N // 128 + 4)
+        d_ov, d_os = pkg.DeviceBuffer(M * N // 4 + 4), _act_buf(pkg, M, N)
         _launch(pkg, "vh_launch_linear_mx", None, d_ov.ptr, d_os.ptr, d_wv.ptr, d_ws.ptr, d_xv.ptr, d_xs.ptr, d_b.ptr,
                 M, K, N, gelu, None)
-        got = mx_ref.dequantize(_bytes(d_ov, M * N).reshape(N // 128, M, 128), _bytes(d_os, M * N // 32).reshape(N // 128, 4, M))[rows]
+        got = mx_ref.dequantize(_bytes(d_ov, M * N).reshape(N // 128, M, 128), _act_scales(d_os, M, N))[rows]
         bmax = np.abs(want).reshape(len(rows), N // 32, 32).max(axis=2, keepdims=True)
         assert (np.abs(got - want).reshape(len(rows), N // 32, 32) <= 2.0 ** -3 * bmax + 1e-6).all()
     else:
@@ -118,12 +133,12 @@ def test_layer_norm_mx_is_layer_norm_then_the_numpy_quantiser(pkg, device, oracl
     x = oracle.synth_fill(rows * E, 11 + rows, 3.0, 0.5).reshape(rows, E)
     d_x, d_g, d_b = _dev(pkg, x), _dev(pkg, weights[4]), _dev(pkg, weights[5])
     d_y = pkg.DeviceBuffer(rows * E)
-    d_v, d_s = pkg.DeviceBuffer(rows * E // 4 + 4), pkg.DeviceBuffer(rows * E // 128 + 4)
+    d_v, d_s = pkg.DeviceBuffer(rows * E // 4 + 4), _act_buf(pkg, rows, E)
     _launch(pkg, "vh_launch_layer_norm", None, d_x.ptr, d_g.ptr, d_b.ptr, d_y.ptr, rows, E, E, E, 1e-6)
     _launch(pkg, "vh_launch_layer_norm_mx", None, d_x.ptr, d_g.ptr, d_b.ptr, d_v.ptr, d_s.ptr, rows, E, E, 1e-6)
     want_v, want_s = mx_ref.quantize(d_y.to_numpy((rows, E)))
     got_v = _bytes(d_v, rows * E).reshape(E // 128, rows, 128)
-    got_s = _bytes(d_s, rows * E // 32).reshape(E // 128, 4, rows)
+    got_s = _act_scales(d_s, rows, E)
     assert np.array_equal(got_s, want_s)
     zero = (want_v & 0x7f) == 0
     assert np.array_equal(got_v[~zero], want_v[~zero]) and np.array_equal(got_v[zero] & 0x7f, want_v[zero] & 0x7f)
@@ -161,7 +176,7 @@ def test_linear_mx_fp16_planes_output_is_the_fp32_result_rounded_to_fp16(pkg, de
     x = oracle.synth_fill(M * K, 810 + M, 1.0, 0.1).reshape(M, K)
     w = oracle.synth_fill(N * K, 811 + N, 0.04, 0.0).reshape(N, K)
     d_b = _dev(pkg, oracle.synth_fill(N, 812, 0.1, 0.0))
-    d_xv, d_xs = _quantize_gpu(pkg, x)
+    d_xv, d_xs = _quantize_gpu(pkg, x, act=True)
     d_wv, d_ws = _quantize_gpu(pkg, w)
     d_o, d_h = pkg.DeviceBuffer(M * N), pkg.DeviceBuffer(M * N // 2 + 1)
     _launch(pkg, "vh_launch_linear_mx", None, d_o.ptr, None, d_wv.ptr, d_ws.ptr, d_xv.ptr, d_xs.ptr, d_b.ptr, M, K, N, 0, None)
@@ -173,19 +188,19 @@ def test_linear_mx_fp16_planes_output_is_the_fp32_result_rounded_to_fp16(pkg, de
 @pytest.mark.parametrize("n_images,tokens", [(1, 197), (3, 197), (2, 5), (40, 33), (2, 1)])
 def test_attention_writing_mx_equals_attention_then_the_row_quantiser(pkg, device, oracle, n_images, tokens):
     """vh_launch_attention_planes_f16_mx = vh_launch_attention_planes_f16 (fp32 rows) followed by
-    vh_launch_quantize_mx_rows, byte for byte (values and scales)."""
+    vh_launch_quantize_mx_act, byte for byte (values and scales)."""
     E, H = 768, 12
     rows = n_images * tokens
     qkv = oracle.synth_fill(rows * 3 * E, 278 + tokens, 1.0, 0.0).reshape(rows, 3 * E)
     planes = np.ascontiguousarray(qkv.astype(np.float16).reshape(rows, 3 * E // 32, 32).transpose(1, 0, 2))
     d_qh = pkg.DeviceBuffer.from_numpy(planes.ravel().view(np.float32))
     d_o = pkg.DeviceBuffer(rows * E)
-    d_v1, d_s1 = pkg.DeviceBuffer(rows * E // 4 + 4), pkg.DeviceBuffer(rows * E // 128 + 4)
-    d_v2, d_s2 = pkg.DeviceBuffer(rows * E // 4 + 4), pkg.DeviceBuffer(rows * E // 128 + 4)
+    d_v1, d_s1 = pkg.DeviceBuffer(rows * E // 4 + 4), _act_buf(pkg, rows, E)
+    d_v2, d_s2 = pkg.DeviceBuffer(rows * E // 4 + 4), _act_buf(pkg, rows, E)
     _launch(pkg, "vh_launch_attention_planes_f16", None, d_qh.ptr, d_o.ptr, 0, n_images, tokens, E, H)
-    _launch(pkg, "vh_launch_quantize_mx_rows", None, d_o.ptr, d_v1.ptr, d_s1.ptr, rows, E)
+    _launch(pkg, "vh_launch_quantize_mx_act", None, d_o.ptr, d_v1.ptr, d_s1.ptr, rows, E)
     _launch(pkg, "vh_launch_attention_planes_f16_mx", None, d_qh.ptr, d_v2.ptr, d_s2.ptr, n_images, tokens, E, H)
-    assert np.array_equal(_bytes(d_s1, rows * E // 32), _bytes(d_s2, rows * E // 32))
+    assert np.array_equal(_act_scales(d_s1, rows, E), _act_scales(d_s2, rows, E))
     assert np.array_equal(_bytes(d_v1, rows * E), _bytes(d_v2, rows * E))
     assert pkg.lib().vh_launch_attention_planes_f16_mx(None, d_qh.ptr, d_v2.ptr, None, n_images, tokens, E, H) != 0
 
@@ -201,12 +216,12 @@ def test_fc1_gelu_of_the_fp8_mode_holds_its_error_bound_for_every_x(pkg, device)
     M, K = len(vals), 256
     x = np.repeat(vals[:, None], K, axis=1)
     w = np.eye(K, dtype=np.float32)
-    d_xv, d_xs = _quantize_gpu(pkg, x)
+    d_xv, d_xs = _quantize_gpu(pkg, x, act=True)
     d_wv, d_ws = _quantize_gpu(pkg, w)
     d_b = _dev(pkg, np.zeros(K, np.float32))
-    d_ov, d_os = pkg.DeviceBuffer(M * K // 4 + 4), pkg.DeviceBuffer(M * K // 128 + 4)
+    d_ov, d_os = pkg.DeviceBuffer(M * K // 4 + 4), _act_buf(pkg, M, K)
     _launch(pkg, "vh_launch_linear_mx", None, d_ov.ptr, d_os.ptr, d_wv.ptr, d_ws.ptr, d_xv.ptr, d_xs.ptr, d_b.ptr, M, K, K, 1, None)
-    got = mx_ref.dequantize(_bytes(d_ov, M * K).reshape(K // 128, M, 128), _bytes(d_os, M * K // 32).reshape(K // 128, 4, M))[:, 0].astype(np.float64)
+    got = mx_ref.dequantize(_bytes(d_ov, M * K).reshape(K // 128, M, 128), _act_scales(d_os, M, K))[:, 0].astype(np.float64)
     v64 = vals.astype(np.float64)
     want = 0.5 * v64 * (1.0 + np.vectorize(erf)(v64 / np.sqrt(2.0)))
     err = np.abs(got - want)

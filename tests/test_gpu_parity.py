@@ -810,7 +810,7 @@ def test_head_dim_80_attention_writing_the_next_operand_equals_rows_then_the_rep
     """vh_launch_attention_planes_f16_hd80_operand: ViT-H/14's attention writing the output projection's operand itself --
     one-part bf16 planes, or the block-scaled fp8 tensor -- although head_dim 80 does not tile the formats' 32-column
     blocks (a workgroup walks head pairs and carries the even head's last half block in registers).  Must equal the
-    fp32-rows kernel followed by vh_launch_split_rows(parts = 1) / vh_launch_quantize_mx_rows, byte for byte
+    fp32-rows kernel followed by vh_launch_split_rows(parts = 1) / vh_launch_quantize_mx_act, byte for byte
     (e4m3 zeros up to their sign)."""
     E, H = 1280, 16
     rows = n_images * tokens
@@ -826,12 +826,15 @@ def test_head_dim_80_attention_writing_the_next_operand_equals_rows_then_the_rep
     _launch(pkg, "vh_launch_attention_planes_f16_hd80_operand", None, d_qh.ptr, d_got.ptr, None, 1, n_images, tokens, E, H)
     assert np.array_equal(d_got.to_numpy().view(np.uint16)[:nb], d_want.to_numpy().view(np.uint16)[:nb])
     # block-scaled fp8
-    d_wv, d_ws = pkg.DeviceBuffer(nb // 4 + 4), pkg.DeviceBuffer(nb // 128 + 4)
-    d_gv, d_gs = pkg.DeviceBuffer(nb // 4 + 4), pkg.DeviceBuffer(nb // 128 + 4)
-    _launch(pkg, "vh_launch_quantize_mx_rows", None, d_rows.ptr, d_wv.ptr, d_ws.ptr, rows, E)
+    import mx_ref
+    sb = mx_ref.act_scale_bytes(rows, E)                         # activation tensors: scale bytes in the activation order
+    d_wv, d_ws = pkg.DeviceBuffer(nb // 4 + 4), pkg.DeviceBuffer(sb // 4 + 4)
+    d_gv, d_gs = pkg.DeviceBuffer(nb // 4 + 4), pkg.DeviceBuffer(sb // 4 + 4)
+    _launch(pkg, "vh_launch_quantize_mx_act", None, d_rows.ptr, d_wv.ptr, d_ws.ptr, rows, E)
     _launch(pkg, "vh_launch_attention_planes_f16_hd80_operand", None, d_qh.ptr, d_gv.ptr, d_gs.ptr, 2, n_images, tokens, E, H)
     wv, gv = d_wv.to_numpy().view(np.uint8)[:nb], d_gv.to_numpy().view(np.uint8)[:nb]
-    assert np.array_equal(d_gs.to_numpy().view(np.uint8)[:nb // 32], d_ws.to_numpy().view(np.uint8)[:nb // 32])
+    assert np.array_equal(mx_ref.from_act_layout(d_gs.to_numpy().view(np.uint8), rows, E),
+                          mx_ref.from_act_layout(d_ws.to_numpy().view(np.uint8), rows, E))
     zero = (wv & 0x7f) == 0
     assert np.array_equal(gv[~zero], wv[~zero]) and np.array_equal(gv[zero] & 0x7f, wv[zero] & 0x7f)
     L = pkg.lib()

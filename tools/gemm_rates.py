@@ -31,13 +31,14 @@ def main():
         res = pkg.DeviceBuffer(M * N) if resid else None
         x3, w3 = pkg.DeviceBuffer(M * K * 3 // 2 + 16), pkg.DeviceBuffer(N * K * 3 // 2 + 16)
         x1, w1 = pkg.DeviceBuffer(M * K // 2 + 16), pkg.DeviceBuffer(N * K // 2 + 16)
-        xv, xs, wv, ws = (pkg.DeviceBuffer(M * K // 4 + 16), pkg.DeviceBuffer(M * K // 128 + 16),
+        # activations carry their MX scale bytes in the activation order (vh_mx_act_scale_bytes), weights in theirs
+        xv, xs, wv, ws = (pkg.DeviceBuffer(M * K // 4 + 16), pkg.DeviceBuffer(L.vh_mx_act_scale_bytes(M, K) // 4 + 16),
                           pkg.DeviceBuffer(N * K // 4 + 16), pkg.DeviceBuffer(N * K // 128 + 16))
-        os_ = pkg.DeviceBuffer(M * N // 128 + 16)
+        os_ = pkg.DeviceBuffer(L.vh_mx_act_scale_bytes(M, N) // 4 + 16)
         chk = pkg.binding.check
         chk(L.vh_launch_split_rows(None, x.ptr, x3.ptr, M, K, 3)); chk(L.vh_launch_split_rows(None, w.ptr, w3.ptr, N, K, 3))
         chk(L.vh_launch_split_rows(None, x.ptr, x1.ptr, M, K, 1)); chk(L.vh_launch_split_rows(None, w.ptr, w1.ptr, N, K, 1))
-        chk(L.vh_launch_quantize_mx_rows(None, x.ptr, xv.ptr, xs.ptr, M, K)); chk(L.vh_launch_quantize_mx_rows(None, w.ptr, wv.ptr, ws.ptr, N, K))
+        chk(L.vh_launch_quantize_mx_act(None, x.ptr, xv.ptr, xs.ptr, M, K)); chk(L.vh_launch_quantize_mx_rows(None, w.ptr, wv.ptr, ws.ptr, N, K))
         planes_out = 1 if gelu else 0          # fc1 writes its consumer's format, the others fp32 rows
         r = res.ptr if resid else None
         legs = {

@@ -71,6 +71,7 @@ int main(int argc, char **argv)
         {"no W DMA                             ", launch_variant<4, 256, EPI_GELU, OUT_MX, 2>},
         {"no A loads                           ", launch_variant<4, 256, EPI_GELU, OUT_MX, 4>},
         {"no A scale-byte loads                ", launch_variant<4, 256, EPI_GELU, OUT_MX, 8>},
+        {"A scales: one dword per 4 K steps    ", launch_variant<4, 256, EPI_GELU, OUT_MX, 2048>},
         {"no DMA, no A loads                   ", launch_variant<4, 256, EPI_GELU, OUT_MX, 6>},
         {"no reads, no DMA, no A loads         ", launch_variant<4, 256, EPI_GELU, OUT_MX, 7>},
         {"no epilogue stores                   ", launch_variant<4, 256, EPI_GELU, OUT_MX, 64>},
@@ -98,6 +99,7 @@ int main(int argc, char **argv)
             {"no W DMA                             ", launch_variant<4, 256, EPI_RESID, OUT_F32, 2>},
             {"no A loads                           ", launch_variant<4, 256, EPI_RESID, OUT_F32, 4>},
             {"no A scale-byte loads                ", launch_variant<4, 256, EPI_RESID, OUT_F32, 8>},
+            {"A scales: one dword per 4 K steps    ", launch_variant<4, 256, EPI_RESID, OUT_F32, 2048>},
             {"no DMA, no A loads                   ", launch_variant<4, 256, EPI_RESID, OUT_F32, 6>},
             {"no reads, no DMA, no A loads         ", launch_variant<4, 256, EPI_RESID, OUT_F32, 7>},
             {"no epilogue stores                   ", launch_variant<4, 256, EPI_RESID, OUT_F32, 64>},

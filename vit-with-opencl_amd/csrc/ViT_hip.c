@@ -823,7 +823,7 @@ static int attention_reduced(vit_hip_ctx *ctx, vh_stream_t s, int n, char *attn_
     else
         OP(VIT_OP_ATTENTION, (rc = qkv_as_planes(ctx) ? vh_launch_attention_planes_f16_hd80(s, ctx->qkv, ctx->hid, n, T, E, H)
                                                       : vh_launch_attention_f16(s, ctx->qkv, ctx->hid, n, T, E, H)) != 0 ? rc :
-                             attn_scales ? vh_launch_quantize_mx_rows(s, ctx->hid, ctx->attn, attn_scales, rows, E)
+                             attn_scales ? vh_launch_quantize_mx_act(s, ctx->hid, ctx->attn, attn_scales, rows, E)
                                          : vh_launch_split_rows(s, ctx->hid, ctx->attn, rows, E, 1));
     return 0;
 fail:

@@ -237,8 +237,8 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
                                 char *d = reinterpret_cast<char *>(out) + ((size_t)ks * prow + orow) * 128 + 32 * blk + 4 * g;
                                 *reinterpret_cast<unsigned *>(d) = pack_fp8x4(lo * mult);
                                 *reinterpret_cast<unsigned *>(d + 16) = pack_fp8x4(hi * mult);
-                                if (g == 0)   /* scales[ks][lane group of block blk][row]: block b is read by lane group 2 (b & 1) + (b >> 1) */
-                                    out_scales[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * prow + orow] = (unsigned char)sbyte;
+                                if (g == 0)
+                                    out_scales[mx_act_scale_index(ks, blk, orow, prow)] = (unsigned char)sbyte;
                             }
                         }
                     };

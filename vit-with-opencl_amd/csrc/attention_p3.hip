@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_p3_kernel(const char *__re
                     *reinterpret_cast<u32x4 *>(out3 + ((size_t)ks * prow + row) * 128 + 32 * blk + 16 * lh) =
                         u32x4{r02[0], r02[1], r13[0], r13[1]};
                     if (lh == 0)
-                        out_scales[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * prow + row] = (unsigned char)sbyte;
+                        out_scales[mx_act_scale_index(ks, blk, row, prow)] = (unsigned char)sbyte;
                     continue;
                 }
                 u32x2 pg[4][OPL];

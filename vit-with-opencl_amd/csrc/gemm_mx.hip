@@ -7,7 +7,8 @@
  *
  * Operand format ("MX planes"), weights [N][K] and activations [rows][K] alike:
  *     values[K/128][rows][128]  e4m3 bytes     K step, row, element
- *     scales[K/128][4][rows]    e8m0 bytes     K step, lane group, row
+ *     scales[K/128][4][rows]    e8m0 bytes     K step, lane group, row        (weights; activations: the same bytes
+ *                                                                              at mx_act_scale_index, vit_kernels.h)
  * so a 16-row fragment of one K step is 2 KiB contiguous.  Block b (0..3) of a row's K step = its elements
  * 32b .. 32b+31.  The instruction's operand map, measured on the device (no ISA text at hand; tests pin it with
  * a numpy statement): lane l = (row l & 15, group j = l >> 4) supplies 32 bytes; its bytes 0-15 belong,
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
         arow[i] = (unsigned)min(m0 + 32 * wave + 16 * i + l15, p.row_end - 1);
         aoff[i] = arow[i] * 128u + 64u * (j4 >> 1) + 16u * (j4 & 1);
     }
-    const size_t a_step = (size_t)p.a_rows * 128, as_step = (size_t)p.a_rows * 4;
+    const size_t a_step = (size_t)p.a_rows * 128;
     const size_t w_step = (size_t)p.N * 128, ws_step = (size_t)p.N * 4;
 
     /* W DMA: value piece pc = rows 8pc .. 8pc+7 (lane fills physical chunk lane & 7 of row 8pc + (lane >> 3) with
@@ -159,16 +160,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
     /* a fragment = two 16-byte halves (kept apart until the MFMA call) and the lane's scale byte */
     i32x4 a0l[2], a0h[2], a1l[2], a1h[2], wl[RING], wh[RING];
     int a0s[2], a1s[2], ws[RING];
+    unsigned a_scales4[2] = {0u, 0u};   /* this lane's A scales of four consecutive K steps (mx_act_scale_index), per row block */
 
     auto load_a = [&](i32x4 (&al)[2], i32x4 (&ah)[2], int (&as)[2], int kt) {
         gchar_t vb = (gchar_t)p.A + (size_t)kt * a_step;
-        gbyte_t sb = (gbyte_t)p.As + (size_t)kt * as_step + (size_t)j4 * p.a_rows;
         asm volatile("" : "+s"(vb));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             al[i] = __builtin_bit_cast(i32x4, *reinterpret_cast<gvec_t>(vb + aoff[i]));
             ah[i] = __builtin_bit_cast(i32x4, *reinterpret_cast<gvec_t>(vb + aoff[i] + 32));
-            as[i] = sb[arow[i]];
+            /* one dword = the scales of K steps 4 (kt >> 2) .. + 3 of (row, lane group), fetched every fourth step; the
+             * instruction takes byte 0 of its scale register (op_sel 0) */
+            if ((kt & 3) == 0)
+                a_scales4[i] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned *>(
+                    (gchar_t)p.As + ((((size_t)(kt >> 2) * 4 + j4) * (size_t)p.a_rows + arow[i]) << 2));
+            as[i] = (int)(a_scales4[i] >> (8 * (kt & 3)));
         }
     };
     auto read_w = [&](int slot, const char *stage, int j) {
@@ -357,6 +363,7 @@ int launch_mx(hipStream_t st, const MxParams &p, int small_only)
 /* fp32 [rows][K] -> MX planes.  One thread per 4 consecutive values, so that a wave reads 1 KiB of a row in one
  * coalesced instruction and writes 256 contiguous bytes; the 8 lanes of a 32-element block share its maximum through
  * three shuffles.  (One thread per block -- 8 loads of 16 B, 128 B apart from its neighbour's -- ran at 3.5 TB/s.) */
+template <bool ACT>   /* ACT: an activation tensor (scale bytes at mx_act_scale_index); otherwise the weights' [K/128][4][rows] */
 __global__ void quantize_mx_rows_kernel(const float *__restrict__ in, char *__restrict__ values, unsigned char *__restrict__ scales,
                                         int rows, int K)
 {
@@ -378,21 +385,43 @@ __global__ void quantize_mx_rows_kernel(const float *__restrict__ in, char *__re
     const int k = 4 * c4, ks = k >> 7, blk = (k >> 5) & 3;
     *reinterpret_cast<unsigned *>(values + ((size_t)ks * rows + row) * 128 + (k & 127)) = pack_fp8x4(v * mult);
     if ((c4 & 7) == 0)
-        scales[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * rows + row] = (unsigned char)sbyte;
+        scales[ACT ? mx_act_scale_index(ks, blk, (size_t)row, rows) : ((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * rows + row] = (unsigned char)sbyte;
 }
 
 } // namespace
 
-extern "C" int vh_launch_quantize_mx_rows(vh_stream_t s, const float *input, void *values, void *scales, int rows, int cols)
+static int quantize_mx(vh_stream_t s, const float *input, void *values, void *scales, int rows, int cols, bool act)
 {
     if (!input || !values || !scales || rows <= 0 || cols <= 0 || cols % 128 != 0 ||
-        (((uintptr_t)input | (uintptr_t)values) & 15))
+        (((uintptr_t)input | (uintptr_t)values) & 15) || (act && ((uintptr_t)scales & 3)))
         return vh_fail(1, "vh_launch_quantize_mx_rows: bad argument (cols %% 128 == 0, 16-byte aligned pointers)");
     const size_t threads = (size_t)rows * (cols / 4);
-    hipLaunchKernelGGL(quantize_mx_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, input,
-                       static_cast<char *>(values), static_cast<unsigned char *>(scales), rows, cols);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (act)
+        hipLaunchKernelGGL(quantize_mx_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, input, static_cast<char *>(values),
+                           static_cast<unsigned char *>(scales), rows, cols);
+    else
+        hipLaunchKernelGGL(quantize_mx_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, input, static_cast<char *>(values),
+                           static_cast<unsigned char *>(scales), rows, cols);
     VH_LAUNCH_CHECK("quantize_mx_rows_kernel");
     return 0;
+}
+
+/* weights [N][K]: scale bytes [K/128][4][N] (the form the GEMM's LDS-DMA moves) */
+extern "C" int vh_launch_quantize_mx_rows(vh_stream_t s, const float *input, void *values, void *scales, int rows, int cols)
+{
+    return quantize_mx(s, input, values, scales, rows, cols, false);
+}
+
+/* activations [rows][K]: scale bytes [ceil(K/512)][4][rows][4] (vit_kernels.h mx_act_scale_index; vh_mx_act_scale_bytes of them) */
+extern "C" int vh_launch_quantize_mx_act(vh_stream_t s, const float *input, void *values, void *scales, int rows, int cols)
+{
+    return quantize_mx(s, input, values, scales, rows, cols, true);
+}
+
+extern "C" size_t vh_mx_act_scale_bytes(int rows, int cols)
+{
+    return rows > 0 && cols > 0 ? (size_t)((cols / 128 + 3) / 4) * 16 * (size_t)rows : 0;
 }
 
 extern "C" int vh_launch_linear_mx(vh_stream_t s, void *output, void *output_scales, const void *weight_values,

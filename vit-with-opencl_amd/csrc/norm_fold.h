@@ -54,8 +54,8 @@ __device__ __forceinline__ void row_norm_terms(const float *stats, int groups, i
 
 /* One 32-column MX scale block of one row, held as 8 consecutive values (lo, hi) by each of the four lanes
  * l15 + 16 j (j = 0..3) of a wave: block maximum by two shuffles, e8m0 scale, e4m3 values; 8-byte store per lane and
- * the scale byte from lane group 0.  Layout of csrc/gemm_mx.hip: values[K/128][rows][128], scales[K/128][4][rows]
- * with block b of a K step read by lane group 2 (b & 1) + (b >> 1).  col32 = first column of the block.
+ * the scale byte from lane group 0.  Layout of csrc/gemm_mx.hip for activations: values[K/128][rows][128], scale bytes
+ * at mx_act_scale_index (vit_kernels.h).  col32 = first column of the block.
  * All four lanes of the block must call it together (the shuffles); only `live` rows are stored. */
 __device__ __forceinline__ void mx_store_block8(const f32x4 &lo, const f32x4 &hi, char *values, unsigned char *scales, int rows,
                                                 size_t row, int col32, int j4, bool live)
@@ -75,7 +75,7 @@ __device__ __forceinline__ void mx_store_block8(const f32x4 &lo, const f32x4 &hi
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2 *>(values + ((size_t)ks * rows + row) * 128 + 32 * blk + 8 * j4) = u32x2{pack_fp8x4(lo * mult), pack_fp8x4(hi * mult)};
     if (j4 == 0)
-        scales[((size_t)ks * 4 + 2 * (blk & 1) + (blk >> 1)) * rows + row] = (unsigned char)sbyte;
+        scales[mx_act_scale_index(ks, blk, row, rows)] = (unsigned char)sbyte;
 }
 
 #endif

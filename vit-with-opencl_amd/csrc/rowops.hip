@@ -198,8 +198,9 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_p3_kernel(const float
 
 /* LayerNorm whose only consumer is the block-scaled fp8 GEMM (gemm_mx.hip): one wave per row as above; a lane
  * holds 4 consecutive values, the 8 lanes 8m .. 8m+7 one 32-element scale block (three shuffles for its maximum);
- * values and scales go through an LDS image in the MX planes' own order ([K step][16 rows][128 B], then
- * [K step][4][16 rows] scale bytes) so that the global stores are contiguous 2 KiB / 16-byte runs. */
+ * values and scales go through an LDS image in the MX tensor's own order ([K step][16 rows][128 B], then the scale
+ * bytes [K steps / 4][4 lane groups][16 rows][4]: vit_kernels.h mx_act_scale_index) so that the global stores are
+ * contiguous 2 KiB runs and one dword per (row, lane group, four K steps). */
 template <int NV, bool FULL>   /* persistent and FULL as layernorm_p3_kernel */
 __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float *__restrict__ in, const float *__restrict__ gamma,
                                                                     const float *__restrict__ beta, char *__restrict__ values,
@@ -208,8 +209,11 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float
 {
     extern __shared__ __attribute__((aligned(16))) char ln_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nvec = E >> 2, ksteps = E >> 7;
+    const int nvec = E >> 2, ksteps = E >> 7, sgroups = (ksteps + 3) >> 2;
     char *lds_scales = ln_lds + ksteps * LN3_ROWS * 128;
+    for (int i = threadIdx.x; i < sgroups * 4 * LN3_ROWS; i += blockDim.x)   /* bytes of K steps beyond the last stay zero */
+        reinterpret_cast<unsigned *>(lds_scales)[i] = 0u;
+    __syncthreads();
     const int ngroups = (rows + LN3_ROWS - 1) / LN3_ROWS, stride = gridDim.x;
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
@@ -260,12 +264,12 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float
                 const int k = 4 * idx, ks = k >> 7, blk = (k >> 5) & 3;
                 *reinterpret_cast<unsigned *>(ln_lds + (ks * LN3_ROWS + wave) * 128 + (k & 127)) = pack_fp8x4(y * mult);
                 if ((lane & 7) == 0)
-                    lds_scales[(ks * 4 + 2 * (blk & 1) + (blk >> 1)) * LN3_ROWS + wave] = (char)sbyte;
+                    lds_scales[((((ks >> 2) * 4 + 2 * (blk & 1) + (blk >> 1)) * LN3_ROWS + wave) << 2) + (ks & 3)] = (char)sbyte;
             }
         }
         lds_barrier();
         /* copy-out: values piece = half a K step's image (8 rows x 128 B = 1 KiB, lane moves 16 B of row l / 8);
-         * scales: one 16-byte run (16 rows) per (K step, lane group) */
+         * scales: one dword (four K steps) per (group of K steps, lane group, row) */
         const int vpieces = ksteps * 2;
         for (int pc = wave; pc < vpieces; pc += LN3_ROWS) {
             const int ks = pc >> 1, r = 8 * (pc & 1) + (lane >> 3);
@@ -273,14 +277,10 @@ __global__ __launch_bounds__(64 * LN3_ROWS) void layernorm_mx_kernel(const float
                 *reinterpret_cast<f32x4 *>(values + ((size_t)ks * rows + row0 + r) * 128 + 16 * (lane & 7)) =
                     *reinterpret_cast<const f32x4 *>(ln_lds + (ks * LN3_ROWS + r) * 128 + 16 * (lane & 7));
         }
-        if (threadIdx.x < ksteps * 4) {
-            unsigned char *dst = scales + (size_t)threadIdx.x * rows + row0;
-            const char *srcs = lds_scales + threadIdx.x * LN3_ROWS;
-            if (row0 + LN3_ROWS <= rows && (((uintptr_t)dst) & 15) == 0)
-                *reinterpret_cast<f32x4 *>(dst) = *reinterpret_cast<const f32x4 *>(srcs);
-            else
-                for (int r = 0; r < LN3_ROWS && row0 + r < rows; ++r)
-                    dst[r] = (unsigned char)srcs[r];
+        if ((int)threadIdx.x < sgroups * 4 * LN3_ROWS) {
+            const int pair = threadIdx.x / LN3_ROWS, r = threadIdx.x % LN3_ROWS;   /* pair = (K-step group, lane group) */
+            if (row0 + r < rows)
+                reinterpret_cast<unsigned *>(scales)[(size_t)pair * rows + row0 + r] = reinterpret_cast<const unsigned *>(lds_scales)[threadIdx.x];
         }
         lds_barrier();
     };
@@ -470,12 +470,12 @@ extern "C" int vh_launch_layer_norm_mx(vh_stream_t s, const float *input, const 
 {
     if (!input || !weight || !bias || !out_values || !out_scales)
         return vh_fail(1, "vh_launch_layer_norm_mx: null pointer argument");
-    if (rows <= 0 || embed_dim <= 0 || embed_dim % 128 != 0 || embed_dim > 2048 || ((uintptr_t)out_values & 15))
+    if (rows <= 0 || embed_dim <= 0 || embed_dim % 128 != 0 || embed_dim > 2048 || ((uintptr_t)out_values & 15) || ((uintptr_t)out_scales & 3))
         return vh_fail(1, "vh_launch_layer_norm_mx: embed_dim=%d must be a multiple of 128, <= 2048, values 16-byte aligned", embed_dim);
     if (in_row_stride % 4 != 0 || in_row_stride < embed_dim)
         return vh_fail(1, "vh_launch_layer_norm_mx: row stride must be a multiple of 4 floats and >= embed_dim");
     const int nv = (embed_dim / 4 + 63) / 64;
-    const size_t lds = (size_t)(embed_dim / 128) * LN3_ROWS * (128 + 4);
+    const size_t lds = (size_t)(embed_dim / 128) * LN3_ROWS * 128 + (size_t)((embed_dim / 128 + 3) / 4) * 4 * LN3_ROWS * 4;
     const int ngroups = (rows + LN3_ROWS - 1) / LN3_ROWS;
     const int cap = 2 * vh_device_cus(vh_current_device());               /* two workgroups of 1024 threads per CU */
     const dim3 grid(ngroups < cap ? ngroups : cap), block(64 * LN3_ROWS);

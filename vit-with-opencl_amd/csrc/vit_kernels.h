@@ -38,6 +38,17 @@ __device__ __forceinline__ void mx_block_scale(float amax, unsigned &scale_byte,
     mult = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);                    /* 2^-e, exact */
 }
 
+/* Scale bytes of an ACTIVATION MX tensor [rows][K]: act_scales[ceil(K/512)][4][rows][4] -- K steps in groups of four, lane
+ * group g (block b of a K step is read by lane group 2 (b & 1) + (b >> 1)), row, K step within the group.  The lane that
+ * owns (row, g) in the GEMM takes its scales of FOUR K steps with one dword load (gemm_mx.hip load_a): with one byte per
+ * (K step, group, row) -- the weights' layout, which travels by LDS-DMA and stays as it is -- every fragment and K step
+ * cost a 64-lane byte load, as dear on the address path as a 16-byte one (K = 3072: 10 % of fc2).  Bytes of K steps
+ * beyond K / 128 in the last group are never written nor used. */
+__device__ __forceinline__ size_t mx_act_scale_index(int ks, int blk, size_t row, int rows)
+{
+    return ((((size_t)(ks >> 2) * 4 + (2 * (blk & 1) + (blk >> 1))) * (size_t)rows + row) << 2) + (size_t)(ks & 3);
+}
+
 /* Records `msg` as the calling thread's last error and returns `code`. */
 int vh_fail(int code, const char *fmt, ...);
 /* Converts a hipError_t into the launcher return convention, recording text. */

@@ -42,7 +42,7 @@ EXPORTS = [
     "vh_launch_split3_rows", "vh_launch_merge3_rows", "vh_launch_layer_norm_p3", "vh_launch_attention_p3",
     "vh_launch_linear_p3", "vh_launch_split_rows", "vh_launch_merge_rows", "vh_launch_layer_norm_planes",
     "vh_launch_attention_planes_bf16", "vh_launch_linear_planes", "vh_launch_attention_planes",
-    "vh_launch_quantize_mx_rows", "vh_launch_linear_mx", "vh_launch_layer_norm_mx",
+    "vh_launch_quantize_mx_rows", "vh_launch_quantize_mx_act", "vh_mx_act_scale_bytes", "vh_launch_linear_mx", "vh_launch_layer_norm_mx",
     "vh_launch_attention_planes_f16", "vh_launch_linear_mx_planes_f16", "vh_launch_attention_planes_f16_mx",
     "vh_launch_attention_planes_f16_hd80", "vh_launch_attention_planes_f16_hd80_operand",
     "vh_launch_gather_rows", "vit_hip_set_last_layer_cls_only",
@@ -195,6 +195,9 @@ def lib() -> C.CDLL:
     L.vh_launch_patch_embed_planes3_norm.argtypes = [voidp] + [voidp] * 6 + [i] * 5 + [voidp, sz, voidp, voidp]
     L.vh_launch_linear_p3_norm.argtypes = [voidp, voidp, i, voidp, voidp, voidp, voidp, voidp, C.c_double, i, i, i, i]
     L.vh_launch_linear_p3_resid_norm.argtypes = [voidp, voidp, voidp, voidp, voidp, voidp, i, i, i, voidp, voidp]
+    L.vh_launch_quantize_mx_act.argtypes = [voidp, voidp, voidp, voidp, i, i]
+    L.vh_mx_act_scale_bytes.argtypes = [i, i]
+    L.vh_mx_act_scale_bytes.restype = sz
     L.vh_launch_fold_gamma.argtypes = [voidp, voidp, voidp, voidp, i, i]
     L.vh_launch_fold_bias.argtypes = [voidp, voidp, voidp, voidp, voidp, i, i]
     L.vh_launch_colsum_operand.argtypes = [voidp, voidp, voidp, voidp, i, i]
