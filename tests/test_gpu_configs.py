@@ -191,3 +191,54 @@ def test_repacked_weights_file_round_trip_for_the_vit_h14_shapes(pkg, device, h1
     lb, pb = b.forward(imgs)
     b.close()
     assert np.isfinite(la).all() and np.array_equal(la, lb) and np.array_equal(pa, pb)
+
+
+TINY = {   # name: (img, patch, classes, embed, depth, heads, mlp, precisions)
+    "17 tokens, 4 heads of 64": (64, 16, 10, 256, 2, 4, 512, ("f32", "f32_fp16x2", "bf16", "fp8")),
+    # 226 tokens > 208: the streaming attention kernel (Q|K|V as fp32 rows); embed 128 = ONE partial sum per row; fp8 needs embed % 256
+    "226 tokens, 2 heads of 64": (240, 16, 3, 128, 1, 2, 256, ("f32", "f32_fp16x2", "bf16")),
+    "17 tokens, 2 heads of 128": (64, 16, 1000, 256, 1, 2, 768, ("f32", "bf16", "fp8")),   # head_dim 128: streaming kernel
+}
+
+
+@pytest.mark.parametrize("shape", sorted(TINY))
+@pytest.mark.parametrize("fold", ["1", "0"])
+def test_a_tiny_custom_config_in_every_precision_vs_port(pkg, device, monkeypatch, fold, shape):
+    """BASELINE config 0 speaks of "the repo's own tiny ViT config": the reference has none (its shape is #define'd,
+    ViT_seq.c:10-21), so here are three through the extended API (TINY above: few tokens, more tokens than the resident
+    attention kernels take, head_dim 128) against the port with the same loop bounds, live ("parity unpinned").  Small enough
+    that every launch is a single ragged tile, the class-token rows are a sixth of all rows, the classifier is 10 columns
+    wide, and the folded LayerNorm adds two partial sums per row (two of the four lanes of a row contribute nothing).
+    fp32 path and its fp16-pair emulation within 1e-4, bf16 within 4e-2, fp8 within 0.15 relative L2; with the LayerNorms
+    folded and with separate launches ($VIT_HIP_LN_FOLD)."""
+    from oracle.oracle import Oracle
+    img, patch, classes, embed, depth, heads, mlp, precisions = TINY[shape]
+    orc = Oracle("vit_b_16")
+    cfg = pkg.preset("vit_b_16")
+    for c in (orc.cfg, cfg):
+        c.img_size, c.patch_size, c.in_chans, c.num_classes = img, patch, 3, classes
+        c.embed_dim, c.depth, c.num_heads, c.mlp_hidden = embed, depth, heads, mlp
+    weights = orc.synth_weights(21)
+    assert len(weights) == 4 + 12 * depth + 4 and pkg.binding.tokens(cfg) == (img // patch) ** 2 + 1
+    imgs = np.stack([orc.synth_image(i) for i in range(5)])
+    want = np.stack([orc.forward(imgs[i], weights)[0] for i in range(5)])
+    monkeypatch.setenv("VIT_HIP_LN_FOLD", fold)
+    if "fp8" not in precisions:      # a shape the block-scaled mode does not take is refused at creation, loudly -- never a fallback
+        with pytest.raises(pkg.VitHipError):
+            pkg.ViTHip(cfg, weights, device=0, max_batch=5, precision="fp8")
+    for precision in precisions:
+        m = pkg.ViTHip(cfg, weights, device=0, max_batch=5, precision=precision)
+        got, probs = m.forward(imgs)
+        again, _ = m.forward(imgs[[3, 0]])
+        m.close()
+        err = float(np.abs(got - want).max())
+        rel = max(_logit_rel_l2(got[i], want[i]) for i in range(5))
+        print(f"tiny config ({shape}), {precision}, fold {fold}: max |dlogit| {err:.3e}, relative L2 {rel:.4f}")
+        assert np.isfinite(got).all() and np.abs(probs.sum(axis=1) - 1.0).max() < 1e-5
+        assert np.array_equal(again, got[[3, 0]])                      # batch-position independence, bit for bit
+        if precision in ("f32", "f32_fp16x2"):
+            assert err <= 1e-4 and np.array_equal(got.argmax(1), want.argmax(1))
+        elif precision == "bf16":
+            assert err <= 4e-2
+        else:
+            assert rel <= 0.15

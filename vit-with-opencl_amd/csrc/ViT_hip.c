@@ -767,7 +767,13 @@ static int alloc_arena(vit_hip_ctx *ctx)
     TRY(vh_malloc((void **)&ctx->attn, rows * E * act));
     TRY(vh_malloc((void **)&ctx->qkv, rows * 3 * E * act));
     {   /* patch geometries that need gathered rows (H/14) borrow the MLP hidden buffer, idle at that point */
-        const size_t ws = vh_patch_embed_workspace(max_batch, cfg->in_chans, cfg->img_size, cfg->patch_size, cfg->embed_dim);
+        size_t ws = vh_patch_embed_workspace(max_batch, cfg->in_chans, cfg->img_size, cfg->patch_size, cfg->embed_dim);
+        if (ctx->wconv16) {   /* the im2row producer's planes: patches x Kp x 2 bytes x parts (a small MLP can be smaller than that) */
+            const size_t grid = (size_t)(cfg->img_size / cfg->patch_size);
+            const size_t planes = (size_t)max_batch * grid * grid * (size_t)vh_patch_planes_k(cfg->in_chans, cfg->patch_size) * 2 *
+                                  (precision == VIT_PRECISION_F32 ? 3 : 1);
+            ws = ws > planes ? ws : planes;
+        }
         const size_t hid_bytes = rows * F * act;
         ctx->ws_bytes = ws > hid_bytes ? ws : hid_bytes;
         TRY(vh_malloc((void **)&ctx->hid, ctx->ws_bytes));
