@@ -203,7 +203,7 @@ TINY = {   # name: (img, patch, classes, embed, depth, heads, mlp, precisions)
 
 @pytest.mark.parametrize("shape", sorted(TINY))
 @pytest.mark.parametrize("fold", ["1", "0"])
-def test_a_tiny_custom_config_in_every_precision_vs_port(pkg, device, monkeypatch, fold, shape):
+def test_a_tiny_custom_config_in_every_precision_vs_port(pkg, device, monkeypatch, tmp_path, fold, shape):
     """BASELINE config 0 speaks of "the repo's own tiny ViT config": the reference has none (its shape is #define'd,
     ViT_seq.c:10-21), so here are three through the extended API (TINY above: few tokens, more tokens than the resident
     attention kernels take, head_dim 128) against the port with the same loop bounds, live ("parity unpinned").  Small enough
@@ -230,7 +230,14 @@ def test_a_tiny_custom_config_in_every_precision_vs_port(pkg, device, monkeypatc
         m = pkg.ViTHip(cfg, weights, device=0, max_batch=5, precision=precision)
         got, probs = m.forward(imgs)
         again, _ = m.forward(imgs[[3, 0]])
+        m.export_planes(tmp_path / f"tiny_{precision}.planes")
         m.close()
+        small = pkg.ViTHip.from_planes(tmp_path / f"tiny_{precision}.planes", device=0, max_batch=2)   # chunks of 2, 2 and 1 images
+        chunked, _ = small.forward(imgs)
+        folded = bool(pkg.lib().vit_hip_ln_fold(small.ctx))
+        small.close()
+        # the context rebuilt from the repacked-weights file (fold terms included), run in ragged chunks: the same bits
+        assert np.array_equal(chunked, got) and folded == (fold == "1" and precision != "f32_fp16x2")     # the fp16-pair emulation never folds
         err = float(np.abs(got - want).max())
         rel = max(_logit_rel_l2(got[i], want[i]) for i in range(5))
         print(f"tiny config ({shape}), {precision}, fold {fold}: max |dlogit| {err:.3e}, relative L2 {rel:.4f}")
