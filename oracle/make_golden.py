@@ -22,6 +22,8 @@ Fixtures (inputs are regenerated from seeds, never stored):
                   IMAGE_COUNT (comparator.c:9) -- for synthetic images 0..99 on rounded weights, written
                   with Main.c's own arg-max loop (Main.c:59-71: pred_idx is NOT reset per image and class 0
                   is never visited, so the line is what the reference's Main.c would print around ViT_seq)
+  b16_seed1.npz   (`make_golden.py other_seed`) logits / probabilities of synthetic images 100, 101 on a SECOND weight set
+                  (seed_base 1), from the reference's ViT_seq.c
   b16_real_image.npz  (`make_golden.py real_image`) the reference's ONE real input -- Data/input-1.bin, a normalised
                   224x224 photograph (spatially correlated pixels, unlike every synthetic image) -- kept as a data fixture,
                   with the logits / probabilities the reference's ViT_seq.c gives for it on the seed-0 synthetic weights
@@ -110,7 +112,23 @@ def real_image() -> None:
                                                                            float(np.sort(lg)[-1] - np.sort(lg)[-2])))
 
 
+def other_seed() -> None:
+    """A second weight set (seed_base 1) and other images (100, 101) through the reference's ViT_seq.c -> b16_seed1.npz:
+    the pinning does not rest on one draw of the synthetic weights."""
+    orc.build()
+    if not orc.have_reference():
+        sys.exit("needs the build container (oracle/_ref/ref_harness)")
+    with tempfile.TemporaryDirectory() as td:
+        rec = orc.run_reference("full", 100, 2, 1, out_path=Path(td) / "seed1.bin")
+    np.savez(GOLD / "b16_seed1.npz", logits=rec["logits"].reshape(2, 1000), probs=rec["probs"].reshape(2, 1000),
+             seed_base=np.array(1), first_image=np.array(100))
+    print("seed 1: argmax", rec["logits"].reshape(2, 1000).argmax(1))
+
+
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "other_seed":
+        other_seed()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "answers100":
         answers100()
         return

@@ -323,6 +323,20 @@ def test_model_on_the_references_real_image(pkg, device, weights, precision):
         assert rel <= 0.15
 
 
+def test_model_on_a_second_weight_set_vs_reference_goldens(pkg, device, oracle):
+    """Synthetic weights of seed_base 1 and images 100, 101 (tests/golden/b16_seed1.npz: the reference's own ViT_seq.c): the
+    fp32 path within 1e-4 with the same arg-max, probabilities within 1e-6 -- the parity does not rest on one weight set."""
+    g = np.load(GOLDEN / "b16_seed1.npz")
+    cfg = pkg.preset("vit_b_16")
+    m = pkg.ViTHip(cfg, oracle.synth_weights(int(g["seed_base"])), device=0, max_batch=2)
+    logits, probs = m.forward(pkg.synth_images(cfg, int(g["first_image"]), 2))
+    m.close()
+    err = np.abs(logits - g["logits"]).max(axis=1)
+    print("second weight set: max |dlogit| per image", err)
+    assert err.max() <= LOGIT_TOL and np.array_equal(logits.argmax(1), g["logits"].argmax(1))
+    assert np.abs(probs - g["probs"]).max() <= 1e-6
+
+
 def test_model_residual_stream_vs_oracle(pkg, model, oracle, weights):
     """Residual stream after all 12 layers for one image vs the oracle (12 s of CPU)."""
     cfg = pkg.preset("vit_b_16")
