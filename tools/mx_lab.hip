@@ -68,6 +68,7 @@ int main(int argc, char **argv)
     std::vector<V> vs = {
         {"product: 128x256 (fc1: GELU, MX out) ", launch_variant<4, 256, EPI_GELU, OUT_MX, 0>},
         {"256x256 tiles, one workgroup per CU  ", launch_variant<8, 256, EPI_GELU, OUT_MX, 0>},
+        {"128x128 tiles, three workgroups/CU   ", launch_variant<4, 128, EPI_GELU, OUT_MX, 0>},
         {"no W DMA                             ", launch_variant<4, 256, EPI_GELU, OUT_MX, 2>},
         {"no A loads                           ", launch_variant<4, 256, EPI_GELU, OUT_MX, 4>},
         {"no A scale-byte loads                ", launch_variant<4, 256, EPI_GELU, OUT_MX, 8>},
@@ -96,6 +97,7 @@ int main(int argc, char **argv)
         vs = {
             {"product: 128x256 (+ residual, fp32)  ", launch_variant<4, 256, EPI_RESID, OUT_F32, 0>},
             {"256x256 tiles                        ", launch_variant<8, 256, EPI_RESID, OUT_F32, 0>},
+            {"128x128 tiles, three workgroups/CU   ", launch_variant<4, 128, EPI_RESID, OUT_F32, 0>},
             {"no W DMA                             ", launch_variant<4, 256, EPI_RESID, OUT_F32, 2>},
             {"no A loads                           ", launch_variant<4, 256, EPI_RESID, OUT_F32, 4>},
             {"no A scale-byte loads                ", launch_variant<4, 256, EPI_RESID, OUT_F32, 8>},

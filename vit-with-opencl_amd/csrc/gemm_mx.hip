@@ -22,7 +22,7 @@
  *
  * Kernel structure = gemm_p3.hip's: tile 256 x 256 (or 128 x 128), every wave owns 32 rows; A fragments go
  * HBM/L2 -> VGPR directly (coalesced thanks to the format), double-buffered one K step ahead; W goes by LDS-DMA
- * into [256][128 B] rows (16-byte chunks swizzled c ^ ((r >> 1) & 7)) plus its 1 KiB of scales, two stages; W
+ * into [256][128 B] rows (16-byte chunks swizzled for the permuted fragment rows, see dma_w) plus its scales, two stages; W
  * fragments are taken through a ring of four in registers; one barrier per K step (128 k = 32 MFMAs per wave)
  * before the last ring's worth of MFMAs.  The same column permutation gives a lane eight consecutive output
  * columns: a planes epilogue quantises (block maximum over the four lanes of a row's 32 columns by two
@@ -72,12 +72,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
 {
     constexpr int BM = 32 * NW, JT = BN / 16, RING = 4;
     constexpr int VALS = BN * 128;                  /* bytes of W values per stage */
-    constexpr int STAGE = VALS + 4 * BN;            /* + its scales [4][BN] */
+    constexpr int SCS = BN + 32;                    /* stride of the four lane groups' scale runs: 8 banks apart (below) */
+    constexpr int STAGE = VALS + 4 * SCS;           /* + its scales [4][BN + 32] */
     constexpr int PW = BN / 8 / NW;                 /* 1-KiB value pieces (8 rows x 128 B) per wave and stage */
     constexpr bool NORM = EPI == EPI_NORM || EPI == EPI_NORM_GELU;
     constexpr bool GELU = EPI == EPI_GELU || EPI == EPI_NORM_GELU;
     constexpr bool OPER = OUTK == OUT_F32_OPER_MX;
-    static_assert(JT % RING == 0 && (BN / 8) % NW == 0 && 4 * BN <= 1024, "tile shape");
+    static_assert(JT % RING == 0 && (BN / 8) % NW == 0 && NW >= 4, "tile shape");
     static_assert(!OPER || (EPI == EPI_RESID && BN % 128 == 0), "operand producers: residual-stream epilogues");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,8 +101,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
     const size_t w_step = (size_t)p.N * 128, ws_step = (size_t)p.N * 4;
 
     /* W DMA: value piece pc = rows 8pc .. 8pc+7 (lane fills physical chunk lane & 7 of row 8pc + (lane >> 3) with
-     * logical chunk phys ^ ((row >> 1) & 7)); the scales [4][BN] of the stage are one more piece (BN = 256) */
-    /* (row >> 1) & 7 with row = 8 pc + (lane >> 3): = 4 (pc & 1) + ((lane >> 4) & 3) */
+     * logical chunk phys ^ f(row)); the scales of the stage: one 16-lane piece per lane group, from waves 0..3.
+     * f(r) = 2 ((r >> 3) & 3) + ((r >> 1) & 1): a fragment reads the 16 rows 8a + c (+ 4b), a, c = 0..3 -- the permuted
+     * order that gives a lane eight consecutive output columns -- and two 128-byte rows share a 256-byte bank row, so
+     * the eight rows of one parity need eight different chunk positions: 2a + (c >> 1).  (Round 3's (r >> 1) & 7 was
+     * made for 16 CONSECUTIVE rows and repeats on rows r, r + 16: SQ_LDS_BANK_CONFLICT 22-37 M cycles per launch,
+     * profiles/r04_pmc_summary_fp8_mode.txt; the bf16 kernel's 64-byte rows never had the problem.)
+     * With row = 8 pc + (lane >> 3): f = 2 (pc & 3) + ((lane >> 4) & 1). */
     const gchar_t wtile = (gchar_t)p.W + (size_t)n0 * 128;
     auto dma_w = [&](int stage, int kt) {
 #pragma unroll
@@ -109,29 +115,29 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
             const int pc = wave * PW + i;
             gchar_t src = wtile + (size_t)kt * w_step + (size_t)pc * 1024;
             asm volatile("" : "+s"(src));
-            const unsigned off = (unsigned)(lane >> 3) * 128u + 16u * ((lane & 7) ^ (4 * (pc & 1) + ((lane >> 4) & 3)));
+            const unsigned off = (unsigned)(lane >> 3) * 128u + 16u * ((lane & 7) ^ (2 * (pc & 3) + ((lane >> 4) & 1)));
             __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(smem + stage * STAGE + pc * 1024), 16, 0, 0);
         }
-        if (wave == 0) {   /* scales: 4 runs of BN bytes -> [4][BN] in LDS: 16 bytes per lane (BN = 256), lanes 0..BN/4-1 */
-            if (lane < BN / 4) {
-                const int jj = lane / (BN / 16), within = lane - jj * (BN / 16);
-                gchar_t src = (gchar_t)p.Ws + (size_t)kt * ws_step + (size_t)jj * p.N + n0 + 16 * within;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + stage * STAGE + VALS), 16, 0, 0);
-            }
+        /* scales: lane group jj's run of BN bytes -> LDS at VALS + jj (BN + 32), by wave jj (16 bytes per lane).  The 16
+         * lanes of a group read scale bytes of rows 8a + c: dwords 0, 2, 4, 6 of the run -- with the runs BN apart (a
+         * multiple of 256 bytes) all four groups hit the same four banks; 32 bytes of padding put them 8 banks apart. */
+        if (wave < 4 && lane < BN / 16) {
+            gchar_t src = (gchar_t)p.Ws + (size_t)kt * ws_step + (size_t)wave * p.N + n0 + 16 * lane;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + stage * STAGE + VALS + wave * SCS), 16, 0, 0);
         }
     };
 
     /* W fragment j = 2s + b, MFMA row l15 = LDS row 32s + 8 (l15 >> 2) + 4b + (l15 & 3); chunk c of row r sits at
-     * c ^ ((r >> 1) & 7); this lane's chunks are 4 (j4 >> 1) + (j4 & 1) and + 2 */
+     * c ^ f(r); this lane's chunks are 4 (j4 >> 1) + (j4 & 1) and + 2 */
     const int rl = 8 * (l15 >> 2) + (l15 & 3);
     const int c0 = 4 * (j4 >> 1) + (j4 & 1);
     unsigned wlo[2], whi[2], wsc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int r = rl + 4 * b, sw = (r >> 1) & 7;
+        const int r = rl + 4 * b, sw = 2 * ((r >> 3) & 3) + ((r >> 1) & 1);
         wlo[b] = (unsigned)r * 128u + 16u * (c0 ^ sw);
         whi[b] = (unsigned)r * 128u + 16u * ((c0 + 2) ^ sw);
-        wsc[b] = (unsigned)VALS + (unsigned)j4 * BN + (unsigned)r;
+        wsc[b] = (unsigned)VALS + (unsigned)j4 * SCS + (unsigned)r;
     }
 
     /* the residual goes into the accumulators with the bias -- (r + bias) + sum: its load runs under the prologue's DMA
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_mx_kernel(const MxParams p)
 template <int NW, int BN, int EPI, int OUTK>
 int launch_mx_tile(hipStream_t st, MxParams p)
 {
-    constexpr int LDS = 2 * (BN * 128 + 4 * BN) + ((EPI == EPI_NORM || EPI == EPI_NORM_GELU) ? 2 * BN * 4 : 0);
+    constexpr int LDS = 2 * (BN * 128 + 4 * (BN + 32)) + ((EPI == EPI_NORM || EPI == EPI_NORM_GELU) ? 2 * BN * 4 : 0);
     VH_SET_LDS_ONCE((gemm_mx_kernel<NW, BN, EPI, OUTK>), LDS);
     p.mtiles = (p.row_end - p.row_begin + 32 * NW - 1) / (32 * NW);
     p.ntiles = p.N / BN;
