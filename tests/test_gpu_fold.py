@@ -146,6 +146,45 @@ def _act_buf(pkg, rows, cols):
     return pkg.DeviceBuffer(mx_ref.act_scale_bytes(rows, cols) // 4 + 4)
 
 
+@pytest.mark.parametrize("M,E,N", [(1, 128, 128), (17, 256, 384), (129, 384, 128), (255, 640, 256), (513, 1280, 384), (1000, 2048, 256)])
+def test_bf16_producer_then_consumer_on_ragged_shapes(pkg, device, oracle, M, E, N):
+    """The two halves of the fold chained as the model chains them, on shapes that are not ViT-B/16's: a residual producer
+    (K = E) leaves x, bf16(x) and 1 .. 16 partial sums per row (E = 128 .. 2048: one to four partials per lane of a row,
+    lanes without any), the consumer (N columns) applies them; M from a single row to ragged multiples of the tiles.
+    Against float64 of the folded formula on the rounded operands, and against LayerNorm -> Linear of the fp32 rows."""
+    a = oracle.synth_fill(M * E, 900 + M, 1.0, 0.1).reshape(M, E)
+    w1 = oracle.synth_fill(E * E, 901 + E, 0.04, 0.0).reshape(E, E)
+    b1 = oracle.synth_fill(E, 902, 0.1, 0.0)
+    r = _residual_rows(oracle, M, E, 903)
+    gamma = (1.0 + oracle.synth_fill(E, 904, 0.3, 0.0)).astype(np.float32)
+    beta = oracle.synth_fill(E, 905, 0.2, 0.0)
+    w2 = oracle.synth_fill(N * E, 906 + N, 0.04, 0.0).reshape(N, E)
+    b2 = oracle.synth_fill(N, 907, 0.1, 0.0)
+    d_a, d_w1, d_b1, d_x, d_g, d_be, d_w2, d_b2 = (_dev(pkg, v) for v in (a, w1, b1, r, gamma, beta, w2, b2))
+    d_a1, d_w11 = pkg.DeviceBuffer((M * E + 1) // 2 + 4), pkg.DeviceBuffer((E * E + 1) // 2)
+    _launch(pkg, "vh_launch_split_rows", None, d_a.ptr, d_a1.ptr, M, E, 1)
+    _launch(pkg, "vh_launch_split_rows", None, d_w1.ptr, d_w11.ptr, E, E, 1)
+    d_op, d_st = pkg.DeviceBuffer((M * E + 1) // 2 + 4), pkg.DeviceBuffer((E // 128) * M * 2)
+    _launch(pkg, "vh_launch_linear_planes_resid_norm", None, d_x.ptr, d_w11.ptr, d_a1.ptr, d_b1.ptr, d_x.ptr, M, E, E, d_op.ptr, None, d_st.ptr)
+    x = d_x.to_numpy((M, E))
+    assert np.array_equal(_planes1_to_f32(d_op, M, E), _bf16_rne(x))
+    stats = d_st.to_numpy((E // 128, M, 2))
+    d_ws, d_w21, d_cs, d_bf = pkg.DeviceBuffer(N * E), pkg.DeviceBuffer((N * E + 1) // 2), pkg.DeviceBuffer(N), pkg.DeviceBuffer(N)
+    _launch(pkg, "vh_launch_fold_gamma", None, d_w2.ptr, d_g.ptr, d_ws.ptr, N, E)
+    _launch(pkg, "vh_launch_split_rows", None, d_ws.ptr, d_w21.ptr, N, E, 1)
+    _launch(pkg, "vh_launch_colsum_operand", None, d_w21.ptr, None, d_cs.ptr, N, E)
+    _launch(pkg, "vh_launch_fold_bias", None, d_w2.ptr, d_be.ptr, d_b2.ptr, d_bf.ptr, N, E)
+    d_o = pkg.DeviceBuffer(M * N)
+    _launch(pkg, "vh_launch_linear_planes_norm", None, d_o.ptr, 0, d_w21.ptr, d_op.ptr, d_st.ptr, d_cs.ptr, d_bf.ptr, EPS, M, E, N, 0)
+    got = d_o.to_numpy((M, N))
+    want = _folded_reference(_bf16_rne(x), stats, _planes1_to_f32(d_w21, N, E), d_cs.to_numpy(), d_bf.to_numpy(), E)
+    assert np.abs(got - want).max() <= 4 * OP_TOL * max(1.0, np.abs(want).max())
+    ref = _ln_rows(x, gamma, beta) @ w2.astype(np.float64).T + b2
+    xr = x.astype(np.float64)
+    amp = np.sqrt((xr * xr).mean(1)) / np.maximum(xr.std(1), 1e-3)
+    assert (np.abs(got - ref).max(1) <= (2.0 ** -7 * amp + 2.0 ** -8) * max(1.0, np.abs(ref).max())).all()
+
+
 def _mx_dev(pkg, x, act):
     """fp32 rows -> (values, scales) device buffers through the library's quantiser -- act: an activation tensor (a GEMM's A
     operand, scale bytes in the activation order), else a weight matrix -- and their numpy dequantisation"""
