@@ -636,8 +636,8 @@ static int linear_planes_norm(vh_stream_t s, void *output, int output_planes, co
         return vh_fail(1, "vh_launch_linear_planes_norm: needs colA %% %d == 0 and colB %% 128 == 0 (%d,%d,%d)", kstep, rowA, colA, colB);
     if (output_planes < 0 || output_planes > 2 || (output_planes == 2 && (doGelu || parts == 3)) || (output_planes == 0 && doGelu))
         return vh_fail(1, "vh_launch_linear_planes_norm: unsupported epilogue combination");
-    if (colA > 16 * 128)
-        return vh_fail(1, "vh_launch_linear_planes_norm: colA=%d: at most 16 partial sums per row (colA <= 2048)", colA);
+    if (colA > 16 * 128 || colA % 128 != 0)
+        return vh_fail(1, "vh_launch_linear_planes_norm: colA=%d: one partial sum per 128 columns, at most 16 per row", colA);
     if ((((uintptr_t)output | (uintptr_t)weight_planes | (uintptr_t)input_planes | (uintptr_t)colsum | (uintptr_t)bias_folded) & 15) != 0 ||
         ((uintptr_t)row_stats & 7) != 0)
         return vh_fail(1, "vh_launch_linear_planes_norm: pointers must be 16-byte aligned (row_stats: 8)");
