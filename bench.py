@@ -528,6 +528,11 @@ def main() -> None:
         p2 = m2.profile_read()
         l2 = d_l2.to_numpy((B, NC))
         l32 = logits_host()
+        # the fold's cancellation exposure: |mean| / std of the residual rows (of the first 64 images, after the last layer)
+        exposure = None
+        if folded2:
+            xt = m2.read_tokens(min(B, 64)).astype(np.float64)
+            exposure = round(float(np.abs(xt.mean(1) / xt.std(1)).max()), 4)
         e2e2 = end_to_end(m2) if (args.model == "vit_b_16" and not args.no_end_to_end) else None
         m2.close()
         fc1_ms2 = p2["fc1_gemm"][0] / max(p2["fc1_gemm"][1], 1)
@@ -538,7 +543,7 @@ def main() -> None:
                  "roofline": {"bound": "mfma", "kernel": "fc1 GEMM of this mode", "achieved": round(fc1_tf, 1), "peak": peak_tf,
                               "unit": "TFLOP/s", "frac": round(fc1_tf / peak_tf, 4), "peak_basis": peak_note, "traffic": None},
                  "end_to_end": e2e2,
-                 "layer_norms_folded": folded2,
+                 "layer_norms_folded": folded2, "residual_rows_max_abs_mean_over_std": exposure,
                  "launches_per_step": {k: cnt // 2 for k, (ms, cnt) in p2.items() if cnt},
                  "kernels_avg_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in p2.items() if cnt}}, l2)
 
