@@ -326,6 +326,29 @@ int main(int argc, char **argv)
             STAG(EPI_GELU, OUT_PLANES, 12000), STAG(EPI_GELU, OUT_PLANES, 16000), STAG(EPI_GELU, OUT_PLANES, 22000),
             {"128x256, no stores, in step      ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 64, 1>},
         };
+    } else if (argc >= 6 && argv[5][0] == 'p' && parts == 3) {   /* "prio": static wave priorities (round 4) */
+        vs = {
+            {"product (fc1: GELU, planes out)   ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0>},
+            {"waves 4-7 at priority 1 in K loop ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 4096>},
+            {"product again                     ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0>},
+            {"all waves at 2 in K loop, 0 after ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 8192>},
+            {"all waves at 1 in K loop, 0 after ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 8192 + 16384>},
+            {"all waves at 3 in K loop, 0 after ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 8192 + 32768>},
+            {"product a third time              ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0>},
+            {"128x128 tiles                     ", launch_variant<4, 128, EPI_GELU, OUT_PLANES, 0>},
+            {"128x128, K loop at 2, epilogue 0  ", launch_variant<4, 128, EPI_GELU, OUT_PLANES, 8192>},
+            {"QKV shape epilogue: 256x256       ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 0>},
+            {"QKV: all waves at 2 in K loop     ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 8192>},
+        };
+    } else if (argc >= 6 && argv[5][0] == 'p' && parts == 1) {
+        vs = {
+            {"256x256 bf16 product (fc1)        ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"waves 4-7 at priority 1 in K loop ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 4096, 1>},
+            {"all waves at 2 in K loop, 0 after ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 8192, 1>},
+            {"128x256, two workgroups per CU    ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"128x256, K loop at 2, epilogue 0  ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 8192, 1>},
+            {"128x256, waves 2-3 at 1 in K loop ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 4096, 1>},
+        };
     } else if (argc >= 6 && parts == 1 && argv[5][0] == 'q') {   /* "qkv-stagger": no GELU, fp16 planes out */
         CK(hipMalloc(&g_slots, 4096 * sizeof(unsigned)));
         vs = {
@@ -359,7 +382,7 @@ int main(int argc, char **argv)
             {"256x256, no stores               ", launch_variant<8, 256, EPI_RESID, OUT_F32, 64, 1>},
         };
     }
-    if (argc >= 6 && parts == 3) {   /* "resid", three parts: the fp32 path's out-projection / fc2 (residual added to the finished sum) */
+    if (argc >= 6 && parts == 3 && argv[5][0] != 'p') {   /* "resid", three parts: the fp32 path's out-projection / fc2 (residual added to the finished sum) */
         float *xres;
         CK(hipMalloc(&xres, (size_t)M * N * 4));
         fill_random<<<(unsigned)(((size_t)M * N + 255) / 256), 256, 0, st>>>(xres, (size_t)M * N, 4u, 1.0f);

@@ -10,14 +10,18 @@
  * [3E/32][rows][32] (the projection's epilogue, output_planes = 2), and one head's K and V -- 2 x 3 planes x 272 rows x
  * 64 B = 102 KB -- are RESIDENT in LDS:
  *  - persistent grid, one workgroup of 9 waves per CU walking (image, head) items; a wave owns a 16-query tile
- *    (v_mfma_f32_16x16x16_f16, S^T = K Q^T so that the probabilities stay in registers as the B operand of
- *    O^T = V^T P^T, exactly as attention_tiled.hip) and the 17 tiles of T = 257 take two rounds per item;
+ *    (S^T = K Q^T so that the probabilities stay in registers as the B operand of O^T = V^T P^T, as in
+ *    attention_tiled.hip) and the 17 tiles of T = 257 take two rounds per item;
+ *  - both products on v_mfma_f32_16x16x32_f16 (round 4; before: the 16-deep v_mfma_f32_16x16x16_f16, which gfx950 issues
+ *    in the SAME 16 cycles -- half the rate, tools/mfma_f16_rate_probe.hip): Q.K^T contracts d in three 32-deep steps
+ *    (80 = 32 + 32 + 16; the lanes of the last step's upper half carry Q = 0), P.V contracts the keys of two 16-key
+ *    tiles per instruction (the lane group's four keys of either tile = the S^T registers it already holds);
  *  - K and V take turns as in attention_p3.hip: V of item n lands (LDS-DMA) under Q.K^T of its first round, K of item
  *    n+1 under the second round's softmax and P.V; three workgroup barriers per item;
  *  - head_dim 80 is not a multiple of the planes' 32 columns: head h starts at column 80h = 32 p0 + 16 sh, so the
  *    three planes p0 .. p0+2 are staged and every 16-wide d group g sits in plane (g + sh) >> 1, half (g + sh) & 1;
- *  - K fragment (16 keys x 4 d per lane group): ds_read_b64 from rows whose 16-byte chunks carry gemm_common.h's
- *    swz64 (conflict-free); V fragment (16 d x 4 keys): ds_read_b64_tr_b16 from linear rows, one per MFMA.
+ *  - K fragment (16 keys x 8 d per lane group): ds_read_b128 from rows whose 16-byte chunks carry gemm_common.h's
+ *    swz64 (conflict-free); V fragment (16 d x 2 x 4 keys): two ds_read_b64_tr_b16 from linear rows per MFMA.
  * Output: fp32 rows [rows][E] (OUTK 0), or the output projection's operand directly -- one-part bf16 planes (OUTK 4) or
  * the block-scaled fp8 tensor (OUTK 8).  head_dim 80 does not tile those formats' 32-column blocks: columns 64-79 of an
  * even head share a block with columns 0-15 of the next head.  For those outputs a workgroup therefore walks head
@@ -37,7 +41,9 @@ namespace {
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int MAX_LDS = 160 * 1024;
 
@@ -62,6 +68,7 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
     static_assert(OUTK == 0 || OUTK == 4 || OUTK == 8, "output kind");
     static_assert(!PAIRS || HD == 80, "the carried half block is written for head_dim 80");
     constexpr int G = HD / 16;                      /* 16-wide d groups */
+    constexpr int GS = (G + 1) / 2;                 /* 32-deep contraction steps of Q.K^T (the last may be half empty) */
     constexpr int PLN = (HD + 16 + 31) / 32;        /* planes staged per operand (any 16-column offset of the head) */
     constexpr int RB = 16 * NJ;                     /* rows per staged plane */
     constexpr int ROUNDS = 2;
@@ -90,11 +97,16 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
         }
     };
 
-    /* per-lane LDS offsets inside a staged plane, for the two halves of a 64-byte row */
-    int kofs[2];
+    /* Q.K^T step s: this lane group contracts the 16-wide d group 2s + (g >> 1), its 8 values 8 (g & 1) .. +7 -- chunk
+     * 2 ((d group + sh) & 1) + (g & 1) of row l15 of plane (d group + sh) >> 1.  Lanes whose d group lies past the head
+     * (the upper half of the last step when G is odd) carry Q = 0 and read the step's lower half again (finite values). */
+    int dgrp[GS];
+    bool dlive[GS];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-        kofs[hf] = l15 * 64 + 16 * ((2 * hf + (g >> 1)) ^ swz64(l15 >> 2)) + 8 * (g & 1);
+    for (int s2 = 0; s2 < GS; ++s2) {
+        dlive[s2] = 2 * s2 + (g >> 1) < G;
+        dgrp[s2] = dlive[s2] ? 2 * s2 + (g >> 1) : 2 * s2;
+    }
     const int vrow = (4 * g + (l15 >> 2)) * 64 + 8 * (l15 & 3);     /* transposed read: lane i addresses row i >> 2, columns 4 (i & 3) .. */
 
     /* the workgroup's n-th item: (image, head) number blockIdx.x + n gridDim.x, or -- PAIRS -- head n & 1 of its
@@ -126,23 +138,26 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
 
             f32x4 S[NJ];
             if (active) {
-                /* this lane's query (MFMA column), the 4 d values of its lane group per 16-wide d group */
-                half4 qh[G];
+                /* this lane's query (MFMA column): the 8 d values of its lane group per 32-deep step */
+                half8 qh[GS];
+                int kofs[GS];
                 const size_t qr = (size_t)b * T + min(q_row, T - 1);
 #pragma unroll
-                for (int s = 0; s < G; ++s) {
-                    const int idx = s + sh;
-                    qh[s] = *reinterpret_cast<const half4 *>(qkvh + ((size_t)(p0 + (idx >> 1)) * prow + qr) * 64 + 32 * (idx & 1) + 8 * g);
+                for (int s2 = 0; s2 < GS; ++s2) {
+                    const int idx = dgrp[s2] + sh, chunk = 2 * (idx & 1) + (g & 1);
+                    qh[s2] = *reinterpret_cast<const half8 *>(qkvh + ((size_t)(p0 + (idx >> 1)) * prow + qr) * 64 + 16 * chunk);
+                    if (!dlive[s2])
+                        qh[s2] = half8{};
+                    kofs[s2] = (idx >> 1) * (RB * 64) + l15 * 64 + 16 * (chunk ^ swz64(l15 >> 2));
                 }
                 /* S^T = K Q^T: rows = keys of tile j, column = this lane's query */
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int s = 0; s < G; ++s) {
-                        const int idx = s + sh;
-                        const half4 kf = *reinterpret_cast<const half4 *>(Kb + (idx >> 1) * (RB * 64) + j * 1024 + ((idx & 1) ? kofs[1] : kofs[0]));
-                        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qh[s], acc, 0, 0, 0);
+                    for (int s2 = 0; s2 < GS; ++s2) {
+                        const half8 kf = *reinterpret_cast<const half8 *>(Kb + j * 1024 + kofs[s2]);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qh[s2], acc, 0, 0, 0);
                     }
                     S[j] = acc;
                 }
@@ -183,21 +198,27 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
                 for (int j = 0; j < NJ; ++j)
                     S[j] *= inv;
 
-                /* O^T = V^T P^T: rows = d of group dt, column = this lane's query; lane group g contracts keys 16j + 4g .. +3 */
+                /* O^T = V^T P^T: rows = d of group dt, column = this lane's query; one MFMA contracts the key tiles 2t and 2t + 1:
+                 * lane group g the keys 32t + 4g .. +3 (slots 0-3) and 32t + 16 + 4g .. +3 (slots 4-7) -- the S^T registers it
+                 * holds.  Keys >= T carry P = 0 exactly (exp2 of -inf) against clamped, finite V rows. */
                 f32x4 O[G];
 #pragma unroll
                 for (int dt = 0; dt < G; ++dt)
                     O[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if (16 * j < T) {                    /* uniform */
-                        const half4 ph = to_half4(S[j]);
+                for (int t = 0; t < (NJ + 1) / 2; ++t) {
+                    if (32 * t < T) {                    /* uniform */
+                        const int j1 = 2 * t + 1 < NJ ? 2 * t + 1 : 2 * t;      /* no second tile: P = 0 against the first one's V */
+                        const half4 pl = to_half4(S[2 * t]), pu = 2 * t + 1 < NJ ? to_half4(S[j1]) : half4{};
+                        const half8 ph = {pl[0], pl[1], pl[2], pl[3], pu[0], pu[1], pu[2], pu[3]};
 #pragma unroll
                         for (int dt = 0; dt < G; ++dt) {
                             const int idx = dt + sh;
-                            const char *vp = Vb + (idx >> 1) * (RB * 64) + j * 1024 + vrow + 32 * (idx & 1);
-                            const s16x4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));
-                            O[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, vt), ph, O[dt], 0, 0, 0);
+                            const char *vp = Vb + (idx >> 1) * (RB * 64) + vrow + 32 * (idx & 1);
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + 2 * t * 1024));
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + j1 * 1024));
+                            O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                __builtin_bit_cast(half8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}), ph, O[dt], 0, 0, 0);
                         }
                     }
                 }
