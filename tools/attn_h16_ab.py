@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Same-box A/B of differently built copies of the library on ONE launcher: the ViT-H/14 attention
+(vh_launch_attention_planes_f16_hd80_operand, 256 images, 257 tokens, 16 heads of 80) timed alternately, in one process,
+on the same device buffers.  Box-to-box spread of bench.py is +-2 %; differences between kernel variants of that size only
+show this way.  Usage: attn_h16_ab.py name=path/to/libvit_hip.so [name=path ...] [kind: 1 = bf16 planes out (default), 2 = MX out]"""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as graft  # noqa: E402
+
+
+def main():
+    libs, kind = [], 1
+    for a in sys.argv[1:]:
+        if "=" in a:
+            name, path = a.split("=", 1)
+            libs.append((name, path))
+        else:
+            kind = int(a)
+    pkg = graft.load_package()
+    L0 = pkg.lib()
+    assert L0.vh_init(0) == 0, L0.vh_last_error()
+    n, T, E, H = 256, 257, 1280, 16
+    rows = n * T
+    rng = np.random.default_rng(5)
+    planes = rng.standard_normal((3 * E // 32, rows, 32), dtype=np.float32).astype(np.float16)
+    d_q = pkg.DeviceBuffer.from_numpy(planes.ravel().view(np.float32))
+    d_o = pkg.DeviceBuffer(rows * E)
+    d_s = pkg.DeviceBuffer(rows * E // 32 + 64)
+    voidp, i = C.c_void_p, C.c_int
+    handles = []
+    for name, path in libs:
+        L = C.CDLL(path)
+        L.vh_init.argtypes = [i]
+        L.vh_last_error.restype = C.c_char_p
+        assert L.vh_init(0) == 0, L.vh_last_error()
+        f = L.vh_launch_attention_planes_f16_hd80_operand
+        f.argtypes = [voidp, voidp, voidp, voidp, i, i, i, i, i]
+        handles.append((name, L, f))
+    outs = {}
+    for name, L, f in handles:      # warm-up + the bytes each variant writes
+        assert f(None, d_q.ptr, d_o.ptr, d_s.ptr if kind == 2 else None, kind, n, T, E, H) == 0, L.vh_last_error()
+        assert L.vh_device_sync() == 0
+        outs[name] = d_o.to_numpy()[: rows * E // (2 if kind == 1 else 4)].copy()
+    ROUNDS, REPS = 8, 20
+    t = {name: [] for name, _, _ in handles}
+    for r in range(ROUNDS):
+        for name, L, f in (handles if r % 2 == 0 else handles[::-1]):
+            L.vh_device_sync()
+            t0 = time.perf_counter()
+            for _ in range(REPS):
+                f(None, d_q.ptr, d_o.ptr, d_s.ptr if kind == 2 else None, kind, n, T, E, H)
+            L.vh_device_sync()
+            t[name].append((time.perf_counter() - t0) / REPS * 1e3)
+    first = handles[0][0]
+    print(f"ViT-H/14 attention, {n} images, output kind {kind}; {ROUNDS} rounds x {REPS} launches per variant, order alternating")
+    for name, _, _ in handles:
+        a = np.array(t[name])
+        same = "bit-identical to " + first if np.array_equal(outs[name], outs[first]) else \
+            f"differs from {first} in {int((outs[name] != outs[first]).sum())} of {outs[first].size} words"
+        print(f"  {name:28s} mean {a.mean():.4f} ms  min {a.min():.4f}  max {a.max():.4f}   ({same})")
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,9 @@
  *    tiles per instruction (the lane group's four keys of either tile = the S^T registers it already holds);
  *  - K and V take turns as in attention_p3.hip: V of item n lands (LDS-DMA) under Q.K^T of its first round, K of item
  *    n+1 under the second round's softmax and P.V; three workgroup barriers per item;
+ *  - Q travels with K (a third staged operand, 3 x 52 KB = 153 KB of LDS): a round's query fragments are ds_read_b128s
+ *    instead of global loads whose latency stood in front of each round's first MFMA (round 4; same-box A/B
+ *    tools/attn_h16_ab.py: -1 % with bf16 planes out, -5 % with MX out, where it also ended the register spills);
  *  - head_dim 80 is not a multiple of the planes' 32 columns: head h starts at column 80h = 32 p0 + 16 sh, so the
  *    three planes p0 .. p0+2 are staged and every 16-wide d group g sits in plane (g + sh) >> 1, half (g + sh) & 1;
  *  - K fragment (16 keys x 8 d per lane group): ds_read_b128 from rows whose 16-byte chunks carry gemm_common.h's
@@ -74,22 +77,22 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
     constexpr int ROUNDS = 2;
     static_assert(HD % 16 == 0 && NJ <= 2 * NW, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Kb = smem, *Vb = smem + PLN * RB * 64;
+    char *Kb = smem, *Vb = smem + PLN * RB * 64, *Qb = smem + 2 * PLN * RB * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int E32 = E >> 5;
     const size_t prow = (size_t)(n_items / H) * T;
 
-    /* LDS-DMA piece p = 16 rows x 64 B of one staged plane; K rows carry the read swizzle, V rows are linear */
-    auto dma = [&](int item, int which /* 1 = K, 2 = V */, char *dst) {
+    /* LDS-DMA piece p = 16 rows x 64 B of one staged plane; Q and K rows carry the read swizzle, V rows are linear */
+    auto dma = [&](int item, int which /* 0 = Q, 1 = K, 2 = V */, char *dst) {
         const int b = item / H, h = item - b * H;
         const int p0 = (HD * h) >> 5;
         for (int p = wave; p < PLN * NJ; p += NW) {
             const int plane = p / NJ, rb = p - plane * NJ;
             const int r = 16 * rb + (lane >> 2);
             int c = lane & 3;
-            if (which == 1)
+            if (which != 2)
                 c ^= swz64(lane >> 4);
             const int pl = min(which * E32 + p0 + plane, 3 * E32 - 1);   /* the window's last plane may lie past V's last: clamp (unused columns) */
             const char *src = qkvh + ((size_t)pl * prow + (size_t)b * T + min(r, T - 1)) * 64 + 16 * c;
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
     if (item >= n_items)
         return;
     dma(item, 1, Kb);
-    __syncthreads();                                     /* K of the first item */
+    dma(item, 0, Qb);
+    __syncthreads();                                     /* K and Q of the first item */
 
     f32x4 carry[2] = {};                                 /* PAIRS: columns 64..79 of the even head, per round */
     for (; item < n_items; item = nth_item(++n)) {
@@ -138,17 +142,17 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
 
             f32x4 S[NJ];
             if (active) {
-                /* this lane's query (MFMA column): the 8 d values of its lane group per 32-deep step */
+                /* this lane's query (MFMA column): the 8 d values of its lane group per 32-deep step, from the staged Q planes
+                 * (row 16 tile + l15: the K fragment's address pattern; rows >= T hold a copy of row T - 1, never stored) */
                 half8 qh[GS];
                 int kofs[GS];
-                const size_t qr = (size_t)b * T + min(q_row, T - 1);
 #pragma unroll
                 for (int s2 = 0; s2 < GS; ++s2) {
                     const int idx = dgrp[s2] + sh, chunk = 2 * (idx & 1) + (g & 1);
-                    qh[s2] = *reinterpret_cast<const half8 *>(qkvh + ((size_t)(p0 + (idx >> 1)) * prow + qr) * 64 + 16 * chunk);
+                    kofs[s2] = (idx >> 1) * (RB * 64) + l15 * 64 + 16 * (chunk ^ swz64(l15 >> 2));
+                    qh[s2] = *reinterpret_cast<const half8 *>(Qb + tile * 1024 + kofs[s2]);
                     if (!dlive[s2])
                         qh[s2] = half8{};
-                    kofs[s2] = (idx >> 1) * (RB * 64) + l15 * 64 + 16 * (chunk ^ swz64(l15 >> 2));
                 }
                 /* S^T = K Q^T: rows = keys of tile j, column = this lane's query */
 #pragma unroll
@@ -165,9 +169,11 @@ __global__ __launch_bounds__(64 * NW) void attention_h16_kernel(const char *__re
             if (rnd == 0) {
                 __syncthreads();                         /* A: V of this item has landed */
             } else {
-                __syncthreads();                         /* A': every wave is done with K of this item */
-                if (next < n_items)
+                __syncthreads();                         /* A': every wave is done with K and Q of this item */
+                if (next < n_items) {
                     dma(next, 1, Kb);
+                    dma(next, 0, Qb);
+                }
             }
             if (active) {
                 /* row softmax per query: register r of tile j is key 16j + 4g + r (attention_tiled.hip) */
@@ -283,7 +289,7 @@ template <int HD, int NJ, int NW, int OUTK>
 int launch_h16(hipStream_t st, const char *qkvh, void *out, void *out_scales, int n_images, int T, int E, int H)
 {
     constexpr int PLN = (HD + 16 + 31) / 32;
-    const size_t lds = (size_t)2 * PLN * 16 * NJ * 64;
+    const size_t lds = (size_t)3 * PLN * 16 * NJ * 64;      /* K, V and Q of one head */
     VH_SET_LDS_ONCE((attention_h16_kernel<HD, NJ, NW, OUTK>), MAX_LDS);
     const int num_cus = vh_device_cus(vh_current_device());
     const int n_items = n_images * H;
