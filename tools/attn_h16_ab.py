@@ -2,7 +2,8 @@
 """Same-box A/B of differently built copies of the library on ONE launcher: the ViT-H/14 attention
 (vh_launch_attention_planes_f16_hd80_operand, 256 images, 257 tokens, 16 heads of 80) timed alternately, in one process,
 on the same device buffers.  Box-to-box spread of bench.py is +-2 %; differences between kernel variants of that size only
-show this way.  Usage: attn_h16_ab.py name=path/to/libvit_hip.so [name=path ...] [kind: 1 = bf16 planes out (default), 2 = MX out]"""
+show this way.  Usage: attn_h16_ab.py name=path/to/libvit_hip.so [name=path ...] [kind: 1 = bf16 planes out (default), 2 = MX out] [b16]
+`b16`: the head-dim-64 kernel instead (attention_p3.hip, one-part form: ViT-B/16, 512 images, 197 tokens, 12 heads)."""
 import ctypes as C
 import sys
 import time
@@ -16,17 +17,19 @@ import __graft_entry__ as graft  # noqa: E402
 
 
 def main():
-    libs, kind = [], 1
+    libs, kind, b16 = [], 1, False
     for a in sys.argv[1:]:
         if "=" in a:
             name, path = a.split("=", 1)
             libs.append((name, path))
+        elif a == "b16":
+            b16 = True
         else:
             kind = int(a)
     pkg = graft.load_package()
     L0 = pkg.lib()
     assert L0.vh_init(0) == 0, L0.vh_last_error()
-    n, T, E, H = 256, 257, 1280, 16
+    n, T, E, H = (512, 197, 768, 12) if b16 else (256, 257, 1280, 16)
     rows = n * T
     rng = np.random.default_rng(5)
     planes = rng.standard_normal((3 * E // 32, rows, 32), dtype=np.float32).astype(np.float16)
@@ -40,8 +43,16 @@ def main():
         L.vh_init.argtypes = [i]
         L.vh_last_error.restype = C.c_char_p
         assert L.vh_init(0) == 0, L.vh_last_error()
-        f = L.vh_launch_attention_planes_f16_hd80_operand
-        f.argtypes = [voidp, voidp, voidp, voidp, i, i, i, i, i]
+        if b16:
+            f1, f2 = L.vh_launch_attention_planes_f16, L.vh_launch_attention_planes_f16_mx
+            f1.argtypes = [voidp, voidp, voidp, i, i, i, i, i]
+            f2.argtypes = [voidp, voidp, voidp, voidp, i, i, i, i]
+
+            def f(st, q, o, sc, knd, n_, t_, e_, h_, f1=f1, f2=f2):
+                return f1(st, q, o, 1, n_, t_, e_, h_) if knd == 1 else f2(st, q, o, sc, n_, t_, e_, h_)
+        else:
+            f = L.vh_launch_attention_planes_f16_hd80_operand
+            f.argtypes = [voidp, voidp, voidp, voidp, i, i, i, i, i]
         handles.append((name, L, f))
     outs = {}
     for name, L, f in handles:      # warm-up + the bytes each variant writes
@@ -59,7 +70,7 @@ def main():
             L.vh_device_sync()
             t[name].append((time.perf_counter() - t0) / REPS * 1e3)
     first = handles[0][0]
-    print(f"ViT-H/14 attention, {n} images, output kind {kind}; {ROUNDS} rounds x {REPS} launches per variant, order alternating")
+    print(f"{'ViT-B/16' if b16 else 'ViT-H/14'} attention, {n} images, output kind {kind}; {ROUNDS} rounds x {REPS} launches per variant, order alternating")
     for name, _, _ in handles:
         a = np.array(t[name])
         same = "bit-identical to " + first if np.array_equal(outs[name], outs[first]) else \

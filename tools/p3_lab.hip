@@ -340,6 +340,18 @@ int main(int argc, char **argv)
             {"QKV shape epilogue: 256x256       ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 0>},
             {"QKV: all waves at 2 in K loop     ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 8192>},
         };
+    } else if (argc >= 6 && argv[5][0] == 'w' && parts == 1) {   /* "waits": LDS reads and counted waits by hand */
+        vs = {
+            {"256x256 bf16 product (fc1)        ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"  LDS reads + counted waits in asm", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 131072, 1>},
+            {"256x256 again                     ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"128x256, two workgroups per CU    ", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+            {"  LDS reads + counted waits in asm", launch_variant<4, 256, EPI_GELU, OUT_PLANES, 131072, 1>},
+            {"no stores, 256x256                ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64, 1>},
+            {"  LDS reads + counted waits in asm", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64 + 131072, 1>},
+            {"QKV epilogue (fp16 planes) 256x256", launch_variant<8, 256, EPI_NONE, OUT_PLANES_H, 0, 1>},
+            {"  LDS reads + counted waits in asm", launch_variant<8, 256, EPI_NONE, OUT_PLANES_H, 131072, 1>},
+        };
     } else if (argc >= 6 && argv[5][0] == 'p' && parts == 1) {
         vs = {
             {"256x256 bf16 product (fc1)        ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
@@ -358,13 +370,15 @@ int main(int argc, char **argv)
             STAG(EPI_NONE, OUT_PLANES_H, 12000), STAG(EPI_NONE, OUT_PLANES_H, 16000),
         };
     } else
-    if (argc >= 6 && parts == 1) {   /* "resid": the residual epilogue (out-projection / fc2 shapes), fp32 rows in place */
+    if (argc >= 6 && parts == 1 && argv[5][0] != 'w') {   /* "resid": the residual epilogue (out-projection / fc2 shapes), fp32 rows in place */
         float *xres;
         CK(hipMalloc(&xres, (size_t)M * N * 4));
         fill_random<<<(unsigned)(((size_t)M * N + 255) / 256), 256, 0, st>>>(xres, (size_t)M * N, 4u, 1.0f);
         p.R = xres; p.C = xres;
         vs = {
             {"128x128, residual in accumulators", launch_variant<4, 128, EPI_RESID, OUT_F32, 0, 1>},
+            {"128x128, <= 128 registers (4/CU) ", launch_variant<4, 128, EPI_RESID, OUT_F32, 65536, 1>},
+            {"128x128 again                    ", launch_variant<4, 128, EPI_RESID, OUT_F32, 0, 1>},
             {"256x256, residual in accumulators", launch_variant<8, 256, EPI_RESID, OUT_F32, 0, 1>},
             {"128x256, residual in accumulators", launch_variant<4, 256, EPI_RESID, OUT_F32, 0, 1>},
             {"128x128, permuted columns        ", launch_variant<4, 128, EPI_RESID, OUT_F32, 256, 1>},
