@@ -66,6 +66,28 @@ def test_bench_two_ranks_launch_themselves_verify_the_gather_and_report_the_cpu_
 
 
 @pytest.mark.gpu
+def test_bench_single_gpu_line_carries_every_leg_without_errors():
+    """The N = 1 line the driver records: besides `value`, `roofline` and the parity block, the secondary legs (bf16 / MX fp8 /
+    fp16-pair modes, class-token-rows-only last layer, end to end, drop-in) -- each leg is guarded in bench.py (a failure is
+    reported in its place), so this test is what keeps a broken leg from passing silently."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "64", "--sustain-s", "0",
+                        "--no-pmc", "--no-cpu-baseline", "--no-in-library-multi"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["dtype"] == "f32" and 0 < out["roofline"]["frac"] < 1
+    for key in ("bf16_gemm_mode", "fp8_block_scaled_gemm_mode", "fp32_fp16x2_emulation_mode", "class_token_rows_only_last_layer",
+                "end_to_end", "drop_in_100"):
+        assert key in out and "error" not in out[key], (key, out.get(key))
+    for key in ("bf16_gemm_mode", "fp8_block_scaled_gemm_mode"):
+        assert out[key]["value"] > out["value"] and out[key]["layer_norms_folded"] is True
+        assert out[key]["launches_per_step"]["layer_norm"] == 1 and 0 <= out[key]["residual_rows_max_abs_mean_over_std"] < 1
+    assert out["class_token_rows_only_last_layer"]["logits_bit_identical_to_full_evaluation"] is True
+
+
+@pytest.mark.gpu
 def test_bench_rccl_branch_with_a_group_of_one():
     """bench.py's RCCL-specific body -- logits in a torch tensor, forward on a torch side stream, dist.gather over the
     nccl (= RCCL) backend enqueued on the same stream, barrier + device synchronise around the timed region -- with a
