@@ -701,6 +701,20 @@ def main() -> None:
             if name in flops:
                 per_launch = flops[name] * B / (cnt // PROF_STEPS)
                 entry["tflops"] = round(per_launch / (avg_ms * 1e-3) / 1e12, 2)
+                if name in ("out_proj_gemm", "fc2_gemm"):
+                    # the two projections that update the fp32 residual stream in place are, in the reduced modes, memory
+                    # kernels with a GEMM inside: report their algorithmic bytes per second next to the FLOP rate (operand in,
+                    # residual rows in and out, and -- LayerNorms folded -- the next projection's operand out)
+                    a_b = {"f32": 6.0, "f32_fp16x2": 4.0, "bf16": 2.0, "fp8": 1.03125}[args.dtype]
+                    if os.environ.get("VIT_HIP_P3", "1") == "0" or os.environ.get("VIT_HIP_GEMM_FP32", "s").startswith("n"):
+                        a_b = 4.0 if args.dtype == "f32" else a_b
+                    rows_all = B * tokens
+                    kdim = cfg.embed_dim if name == "out_proj_gemm" else cfg.mlp_hidden
+                    nbytes = rows_all * (kdim * a_b + cfg.embed_dim * 8.0)
+                    if bool(L.vit_hip_ln_fold(model.ctx)):
+                        nbytes += rows_all * cfg.embed_dim * a_b
+                    entry["hbm_gbs"] = round(nbytes / (avg_ms * 1e-3) / 1e9, 1)
+                    entry["frac_hbm_peak"] = round(entry["hbm_gbs"] / PEAK_HBM_GBS, 4)
             elif name == "layer_norm":
                 # algorithmic bytes: read one [rows][E] fp32 tensor, write it as fp32 or (pre-split path) as three
                 # bf16 parts = 6 bytes per value (the final LN is tiny)
