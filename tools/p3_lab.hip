@@ -206,7 +206,7 @@ void launch_m32(hipStream_t st, P3Params p)
 template <int NW, int BN, int EPI, int OUTK, int LAB, int NPL = 3>
 void launch_variant(hipStream_t st, P3Params p)
 {
-    constexpr int LDS = 2 * (NPL == 3 ? 1 : P1_KG) * NPL * BN * 64;
+    constexpr int LDS = ((LAB & 262144) ? 3 : 2) * (NPL == 3 ? 1 : P1_KG) * NPL * BN * 64;
     static bool set = false;
     if (!set) { CK(hipFuncSetAttribute((const void *)gemm_p3_kernel<NW, BN, EPI, OUTK, NPL, LAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
     p.mtiles = (p.row_end - p.row_begin + 32 * NW - 1) / (32 * NW);
@@ -340,6 +340,25 @@ int main(int argc, char **argv)
             {"QKV shape epilogue: 256x256       ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 0>},
             {"QKV: all waves at 2 in K loop     ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 8192>},
         };
+    } else if (argc >= 6 && argv[5][0] == 'h') {   /* "half-step": waves NW/2.. half a K step behind their SIMD partners */
+        if (parts == 1)
+            vs = {
+                {"256x256 bf16 product (fc1)        ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+                {"  waves 4-7 half a step behind    ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 262144, 1>},
+                {"256x256 again                     ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
+                {"QKV epilogue (fp16 planes) 256x256", launch_variant<8, 256, EPI_NONE, OUT_PLANES_H, 0, 1>},
+                {"  waves 4-7 half a step behind    ", launch_variant<8, 256, EPI_NONE, OUT_PLANES_H, 262144, 1>},
+                {"no stores, 256x256                ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64, 1>},
+                {"  waves 4-7 half a step behind    ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 64 + 262144, 1>},
+            };
+        else
+            vs = {
+                {"product (fc1: GELU, planes out)   ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0>},
+                {"  waves 4-7 half a step behind    ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 262144>},
+                {"product again                     ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0>},
+                {"QKV epilogue: 256x256             ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 0>},
+                {"  waves 4-7 half a step behind    ", launch_variant<8, 256, EPI_NONE, OUT_PLANES, 262144>},
+            };
     } else if (argc >= 6 && argv[5][0] == 'w' && parts == 1) {   /* "waits": LDS reads and counted waits by hand */
         vs = {
             {"256x256 bf16 product (fc1)        ", launch_variant<8, 256, EPI_GELU, OUT_PLANES, 0, 1>},
@@ -370,7 +389,7 @@ int main(int argc, char **argv)
             STAG(EPI_NONE, OUT_PLANES_H, 12000), STAG(EPI_NONE, OUT_PLANES_H, 16000),
         };
     } else
-    if (argc >= 6 && parts == 1 && argv[5][0] != 'w') {   /* "resid": the residual epilogue (out-projection / fc2 shapes), fp32 rows in place */
+    if (argc >= 6 && parts == 1 && argv[5][0] != 'w' && argv[5][0] != 'h') {   /* "resid": the residual epilogue (out-projection / fc2 shapes), fp32 rows in place */
         float *xres;
         CK(hipMalloc(&xres, (size_t)M * N * 4));
         fill_random<<<(unsigned)(((size_t)M * N + 255) / 256), 256, 0, st>>>(xres, (size_t)M * N, 4u, 1.0f);
@@ -396,7 +415,7 @@ int main(int argc, char **argv)
             {"256x256, no stores               ", launch_variant<8, 256, EPI_RESID, OUT_F32, 64, 1>},
         };
     }
-    if (argc >= 6 && parts == 3 && argv[5][0] != 'p') {   /* "resid", three parts: the fp32 path's out-projection / fc2 (residual added to the finished sum) */
+    if (argc >= 6 && parts == 3 && argv[5][0] != 'p' && argv[5][0] != 'h') {   /* "resid", three parts: the fp32 path's out-projection / fc2 (residual added to the finished sum) */
         float *xres;
         CK(hipMalloc(&xres, (size_t)M * N * 4));
         fill_random<<<(unsigned)(((size_t)M * N + 255) / 256), 256, 0, st>>>(xres, (size_t)M * N, 4u, 1.0f);
@@ -414,6 +433,24 @@ int main(int argc, char **argv)
             {"256x256, no residual read        ", launch_variant<8, 256, EPI_NONE, OUT_F32, 0>},
             {"256x256, no stores               ", launch_variant<8, 256, EPI_RESID, OUT_F32, 64>},
         };
+    }
+    if (argc >= 6 && argv[5][0] == 'h') {   /* the staggered variant must write the same bytes as the product kernel */
+        const size_t nbytes = (size_t)M * N * 2 * parts, probe = nbytes < ((size_t)64 << 20) ? nbytes : ((size_t)64 << 20);
+        std::vector<unsigned char> ha(2 * probe), hb(2 * probe);
+        CK(hipMemsetAsync(c3, 0, nbytes, st));
+        vs[0].fn(st, p);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(ha.data(), c3, probe, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ha.data() + probe, (char *)c3 + nbytes - probe, probe, hipMemcpyDeviceToHost));
+        CK(hipMemsetAsync(c3, 0, nbytes, st));
+        vs[1].fn(st, p);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(hb.data(), c3, probe, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hb.data() + probe, (char *)c3 + nbytes - probe, probe, hipMemcpyDeviceToHost));
+        size_t diff = 0, nz = 0;
+        for (size_t i = 0; i < 2 * probe; ++i) { diff += ha[i] != hb[i]; nz += ha[i] != 0; }
+        printf("half-step variant against the product kernel, first and last %zu MB of the output: %zu bytes differ (%zu non-zero bytes compared)\n",
+               probe >> 20, diff, nz);
     }
     const int ROUNDS = 4, REPS = 10;
     std::vector<double> best(vs.size(), 1e30), sum(vs.size(), 0.0);
