@@ -8,7 +8,7 @@
  * 64-query workgroup streams the whole K and V of its head through LDS in 5 + 5 chunk steps, each a load latency long
  * -- 0.63 ms per layer where the matrix work is 0.05.  Here Q|K|V arrive as one-part fp16 planes
  * [3E/32][rows][32] (the projection's epilogue, output_planes = 2), and one head's K and V -- 2 x 3 planes x 272 rows x
- * 64 B = 102 KB -- are RESIDENT in LDS:
+ * 64 B = 102 KB -- are RESIDENT in LDS (since round 4 its Q as well: 153 KB):
  *  - persistent grid, one workgroup of 9 waves per CU walking (image, head) items; a wave owns a 16-query tile
  *    (S^T = K Q^T so that the probabilities stay in registers as the B operand of O^T = V^T P^T, as in
  *    attention_tiled.hip) and the 17 tiles of T = 257 take two rounds per item;
