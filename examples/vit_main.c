@@ -62,9 +62,18 @@ int main(int argc, char **argv)
     if (images == NULL)
         return 100;
     const int n = images->n;
-    float **probabilities = (float **)malloc(sizeof(float *) * (size_t)n);
-    for (int i = 0; i < n; ++i)
+    float **probabilities = (float **)malloc(sizeof(float *) * (size_t)(n > 0 ? n : 1));
+    if (probabilities == NULL) {
+        fprintf(stderr, "vit_main: out of memory (%d result rows)\n", n);
+        return 101;
+    }
+    for (int i = 0; i < n; ++i) {
         probabilities[i] = (float *)malloc(sizeof(float) * NUM_CLASSES);
+        if (probabilities[i] == NULL) {
+            fprintf(stderr, "vit_main: out of memory (result row %d of %d)\n", i, n);
+            return 101;
+        }
+    }
 
     printf("=====================Start========================\n");
     const double t0 = wall();

@@ -193,6 +193,8 @@ int vit_hip_forward_device_multi(vit_hip_multi *m, const float *const *d_images,
     int rc = gather_state(m, &gs);
     if (rc)
         return rc;
+    if (!gs)
+        return fail(114, "vit_hip_forward_device_multi: no gather state", NULL);
     const size_t NC = (size_t)vit_hip_config(vit_hip_multi_ctx(m, 0))->num_classes;
 
     /* every shard's forward, asynchronous on its device's stream, entered from its own host thread */
